@@ -1,0 +1,145 @@
+/*
+ * marl_amd.h — C ABI of libmarl_amd.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for the one hot path this repository replaces in
+ * BMDACMER/marl: the batched envs/edge_computing step + observation, the GAE
+ * reverse scan, and the discriminator reward evaluation.  All citations are
+ * path:line inside the reference tree.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative EC_E* code; nothing
+ *     throws across the ABI; ec_last_error() returns a thread-local message.
+ *   - unless a parameter says "host", array arguments are DEVICE pointers owned
+ *     by the caller (contiguous, dtype exactly as declared).
+ *   - work is enqueued on the caller's HIP stream (void* = hipStream_t, NULL =
+ *     the null stream); no hidden synchronisation except where documented.
+ *   - a handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef MARL_AMD_H
+#define MARL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EC_OK 0
+#define EC_EINVAL (-1)  /* bad argument / shape */
+#define EC_EHIP (-2)    /* HIP runtime error */
+#define EC_ENOMEM (-3)
+#define EC_ESTATE (-4)  /* device status word reports a fault (see ec_status) */
+
+/* Bits of the device status word returned by ec_status(). */
+#define EC_ST_BAD_ACTION 1u      /* action is neither a neighbour, self nor idle: the reference divides by a
+                                    zero transmission rate (edge_node.py:227) -> ZeroDivisionError */
+#define EC_ST_BUFFER_OVERFLOW 2u /* buffer_queue ring capacity exceeded */
+#define EC_ST_RECV_OVERFLOW 4u   /* a receiving_queues[src] ring capacity exceeded */
+#define EC_ST_WAIT_OVERFLOW 8u   /* execution_queue ring capacity exceeded */
+#define EC_ST_TICK_OVERFLOW 16u  /* a timer exceeded the tick LUT (cfg.max_ticks) */
+#define EC_ST_HOP_OVERFLOW 32u   /* hop >= hop_hist_len on success; counted in the last bin */
+
+/* Environment constants: the fields of the reference's argparse namespace that the step reads
+ * (envs/edge_computing/multihop/edge_computing_config.py:1-49). */
+typedef struct ec_config {
+    int32_t n_nodes;        /* edge_node_num (= n_agents); n_actions = n_nodes + 1 */
+    int32_t episode_limit;  /* episode_limit */
+    int32_t mini_slots;     /* mini_time_slot_num */
+    int32_t k;              /* k: tasks executing in parallel per node */
+    double mini_time_slot;  /* mini_time_slot */
+    double deadline;        /* deadline */
+    double task_size_min, task_size_max;             /* KB, task.py:11 */
+    double task_complexity_min, task_complexity_max; /* cycles/bit, task.py:12 */
+    double task_drop_penalty, task_failure_penalty, task_success_reward, task_hop_penalty;
+    double execution_failure_rate_max; /* obs[0] normaliser, edge_node.py:112 */
+    double task_probability_max;       /* obs[2] normaliser, edge_node.py:116 */
+    double core_norm;                  /* cpu_core_list[-1], obs[1] normaliser, edge_node.py:114 */
+    double rl_queue_coeff;             /* edge_node.py:186-187 */
+    int64_t task_seed;    /* env e, node i seeds RandomState(task_seed + env_id_base + e + i)     */
+    int64_t failure_seed; /* (parallel_episode_runner.py:19-20 + edge_node.py:28-29)              */
+    int32_t hop_hist_len; /* bins of the cumulative max_hop_dict histogram (edge_node.py:287-290) */
+    int32_t cap_buffer;   /* ring capacities per node (records); 0 = derive a bound from the config */
+    int32_t cap_recv;
+    int32_t cap_wait;
+    int32_t max_ticks;    /* tick LUT length; 0 = mini_slots * (episode_limit + 2) */
+    int32_t reserved;
+} ec_config;
+
+/* Static per-node tables (HOST pointers, row-major), built once per process exactly as
+ * EdgeNode.__init__ does (edge_node.py:22-85) from generate_graph (network_graph.py:219-264). */
+typedef struct ec_topology {
+    const int32_t* cores;       /* [N]   cpu_core_num, edge_node.py:31 */
+    const double* task_p;       /* [N]   task_probability, edge_node.py:34 */
+    const double* efr;          /* [N]   execution_failure_rate, edge_node.py:57 */
+    const double* cpu_capacity; /* [N]   edge_node.py:33 */
+    const double* queue_len;    /* [N]   execution_queue_len, edge_node.py:64 */
+    const double* rate;         /* [N,N] transmission_rates, 0 where not adjacent, edge_node.py:43-52 */
+    const double* tfr;          /* [N,N] transmission_failure_rates, edge_node.py:43-52,60-61 */
+    const uint8_t* adj;         /* [N,N+1] 1 where j in node.actions (neighbours + self), edge_node.py:54-56 */
+} ec_topology;
+
+typedef struct ec_env* ec_handle;
+
+/* --- environment: replaces EdgeComputingEnv for a batch of n_envs instances ------------------- */
+
+/* EdgeComputingEnv.__init__ (edge_computing_env.py:8-30) for envs [env_id_base, env_id_base+n_envs):
+ * seeds both MT19937 streams of every node and performs the constructor's generate_task() pass
+ * (edge_computing_env.py:17-18).  Synchronous. */
+int ec_create(const ec_config* cfg, const ec_topology* topo, int64_t n_envs, int64_t env_id_base,
+              int device, ec_handle* out);
+int ec_destroy(ec_handle h);
+
+/* EdgeComputingEnv.reset (edge_computing_env.py:145-148, edge_node.py:171-177): clears queues and
+ * current_step only; RNG cursors, max_hop_dict and node parameters persist. */
+int ec_reset(ec_handle h, void* stream);
+
+/* get_obs + get_avail_actions (edge_computing_env.py:32-37,73-77; edge_node.py:109-136,179-197).
+ * obs [B,N,9] f32 (fp64 arithmetic, rounded once), avail [B,N,N+1] i32. Either may be NULL. */
+int ec_observe(ec_handle h, float* obs, int32_t* avail, void* stream);
+
+/* EdgeComputingEnv.step (edge_computing_env.py:84-143) for all envs.
+ *   actions     [B,N] i64   (dtype of episode_buffer.py:9)
+ *   reward      [B]   f32   fp64 sum in the reference's order, rounded once
+ *   terminated  [B]   u8
+ *   counters    [B,4] i32   finish, success, drop, failure (info dict, edge_computing_env.py:130-135)
+ *   completion_time [B] f32 info["task_completion_time"]
+ *   hop_hist    [B,H] i32 or NULL: cumulative max_hop_dict (never cleared, edge_node.py:82)
+ *   next_obs / next_avail: optional fused observation of the post-step state (NULL to skip) */
+int ec_step(ec_handle h, const int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
+            float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail, void* stream);
+
+/* Uniform choice over the availability mask (stands in for action_selectors.py:6-8 with a
+ * counter-based device RNG; NOT stream-compatible with torch's generator). avail [rows,A] i32,
+ * actions [rows] i64. */
+int ec_random_policy(const int32_t* avail, int64_t rows, int32_t n_actions, uint64_t seed, uint64_t counter,
+                     int64_t* actions, void* stream);
+
+/* Device status word (EC_ST_* bits, sticky until cleared). Synchronises the stream. */
+int ec_status(ec_handle h, uint32_t* status_host, int clear, void* stream);
+
+/* Parity-test helpers. Synchronous.
+ * ec_debug_dump: every live task of env `env` as rows of 11 doubles
+ *   [node, qtype, pos, size, cycles, hop, ewt, cet, twt, ctt, bwt]  (timers in mini-slot ticks)
+ *   qtype: 0 new_task, 1 buffer_queue, 2 execution_queue, 3 executing_queue, 4+src receiving_queues[src]
+ * rows_host holds max_rows rows; *n_rows_host receives the number written (or needed, if larger). */
+int ec_debug_dump(ec_handle h, int64_t env, double* rows_host, int64_t max_rows, int64_t* n_rows_host);
+/* words consumed so far from each MT19937 stream: cursors_host [B,N,2] (task, failure) u64 */
+int ec_debug_rng_cursors(ec_handle h, uint64_t* cursors_host);
+/* geometry chosen by ec_create: {B, N, k, D(max in-degree), cap_buffer, cap_recv, cap_wait, max_ticks,
+ * threads_per_block, envs_per_block, state_bytes_lo, state_bytes_hi} */
+int ec_info(ec_handle h, int64_t* info_host, int32_t n);
+
+/* --- GAE: replaces utils/advantage_utils.py:4-9 ------------------------------------------------ */
+/* r, v, nv, m, adv: [B,T,N] f32 contiguous (the reference's trailing unit dim is a view).
+ * Evaluation order is the reference's, without FMA contraction, so results are bit-identical to
+ * the fp32 torch loop. */
+int ec_gae(const float* r, const float* v, const float* nv, const float* m, float* adv, int64_t B, int64_t T,
+           int64_t N, float gamma, float gamma_lambda, void* stream);
+
+const char* ec_last_error(void);
+const char* ec_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARL_AMD_H */

@@ -1,0 +1,592 @@
+/*
+ * ec_oracle.c — TEST INFRASTRUCTURE ONLY.  A scalar CPU restatement of the reference's
+ * edge_computing environment (BMDACMER/marl, pure Python), used as the parity checker for the
+ * HIP path and as the timed "port" CPU baseline in bench.py.  Nothing under marl_amd/ may import,
+ * link or call this file.
+ *
+ * It follows the reference statement by statement, keeps every timer as an fp64 value that is
+ * incremented by mini_time_slot (NOT as tick counters), and keeps real FIFO queues of task
+ * structs, so that it is an independent check of the event-driven/tick-LUT formulation the GPU
+ * kernels use.  Pinned against tests/golden/{rng,env10,env10d,env40}.npz, which were produced by
+ * importing the reference (tests/golden/make_golden.py).
+ *
+ * Citations are path:line in the reference tree.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/marl_amd.h"
+
+/* ---------------------------------------------------------------- MT19937 (numpy RandomState) */
+typedef struct {
+    uint32_t mt[624];
+    int pos;
+    uint64_t consumed; /* 32-bit words drawn so far */
+} oc_mt;
+
+/* numpy _legacy_seeding with an int seed == init_genrand (edge_node.py:28-29) */
+static void mt_seed(oc_mt* s, uint32_t seed) {
+    for (int i = 0; i < 624; i++) {
+        s->mt[i] = seed;
+        seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)(i + 1);
+    }
+    s->pos = 624;
+    s->consumed = 0;
+}
+
+static uint32_t mt_u32(oc_mt* s) {
+    if (s->pos == 624) {
+        uint32_t* mt = s->mt;
+        int i;
+        for (i = 0; i < 624 - 397; i++) {
+            uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
+            mt[i] = mt[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        for (; i < 623; i++) {
+            uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
+            mt[i] = mt[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+        mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        s->pos = 0;
+    }
+    uint32_t y = s->mt[s->pos++];
+    s->consumed++;
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+/* random_sample(): 53-bit double from two words */
+static double mt_double(oc_mt* s) {
+    uint32_t a = mt_u32(s) >> 5, b = mt_u32(s) >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+/* uniform(lo, hi) = lo + (hi - lo) * random_sample() */
+static double mt_uniform(oc_mt* s, double lo, double hi) { return lo + (hi - lo) * mt_double(s); }
+
+/* numpy legacy binomial, inversion branch (the only one n = 1 can reach) */
+static long binomial_inversion(oc_mt* s, long n, double p) {
+    double q = 1.0 - p;
+    double qn = exp(n * log(q));
+    double np = n * p;
+    double bd = np + 10.0 * sqrt(np * q + 1);
+    long bound = (long)((double)n < bd ? (double)n : bd);
+    long X = 0;
+    double px = qn;
+    double U = mt_double(s);
+    while (U > px) {
+        X++;
+        if (X > bound) {
+            X = 0;
+            px = qn;
+            U = mt_double(s);
+        } else {
+            U -= px;
+            px = ((n - X + 1) * p * px) / (X * q);
+        }
+    }
+    return X;
+}
+
+static long mt_binomial(oc_mt* s, long n, double p) {
+    if (p <= 0.5) return binomial_inversion(s, n, p);
+    return n - binomial_inversion(s, n, 1.0 - p);
+}
+
+/* exported for the RNG pin test */
+void oc_rng_doubles(uint32_t seed, int64_t n, double* out) {
+    oc_mt s;
+    mt_seed(&s, seed);
+    for (int64_t i = 0; i < n; i++) out[i] = mt_double(&s);
+}
+
+/* generate_task draw pattern: rows of [arrival, id, size, cycles] */
+void oc_rng_task_draws(uint32_t seed, double p, int64_t n, double smin, double smax, double cmin, double cmax,
+                       double* out) {
+    oc_mt s;
+    mt_seed(&s, seed);
+    for (int64_t i = 0; i < n; i++) {
+        long arr = mt_binomial(&s, 1, p);
+        out[4 * i] = (double)arr;
+        if (arr == 1) {
+            out[4 * i + 1] = mt_double(&s);
+            double size = mt_uniform(&s, smin, smax) * 1024 * 8;
+            out[4 * i + 2] = size;
+            out[4 * i + 3] = mt_uniform(&s, cmin, cmax) * size;
+        } else {
+            out[4 * i + 1] = out[4 * i + 2] = out[4 * i + 3] = -1.0;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- task + queues */
+typedef struct {
+    double id, size, cycles; /* task.py:10-12 */
+    double deadline;
+    double twt, tt, ctt; /* transmission waiting / required / current, task.py:16-18 */
+    double ewt, et, cet; /* execute waiting / required / current, task.py:20-22 */
+    double bwt;          /* buffer waiting, task.py:24 */
+    double efr, tfr;     /* task.py:26,28 */
+    int hop;             /* task.py:31 */
+} oc_task;
+
+typedef struct {
+    oc_task* v;
+    int len, cap;
+} oc_q;
+
+static void q_push(oc_q* q, const oc_task* t) {
+    if (q->len == q->cap) {
+        q->cap = q->cap ? 2 * q->cap : 8;
+        q->v = (oc_task*)realloc(q->v, sizeof(oc_task) * q->cap);
+    }
+    q->v[q->len++] = *t;
+}
+static oc_task q_popleft(oc_q* q) {
+    oc_task t = q->v[0];
+    q->len--;
+    memmove(q->v, q->v + 1, sizeof(oc_task) * q->len);
+    return t;
+}
+static void q_remove_at(oc_q* q, int i) {
+    q->len--;
+    memmove(q->v + i, q->v + i + 1, sizeof(oc_task) * (q->len - i));
+}
+
+typedef struct {
+    /* static (edge_node.py:22-64) */
+    int id, cores;
+    double cap, p, efr, qlen;
+    oc_mt task_rng, fail_rng;
+    /* queues (edge_node.py:62-68) */
+    oc_q execution, executing, buffer;
+    oc_q* recv; /* [N] */
+    int has_new;
+    oc_task new_task;
+    /* step stats (edge_node.py:76-84) */
+    double completion_time, reward;
+    long failure, drop, finish, success;
+    long* hop_hist; /* [H] cumulative max_hop_dict */
+    long max_execution_len, max_executing_len;
+} oc_node;
+
+typedef struct {
+    oc_node* nodes;
+    int current_step;
+} oc_one;
+
+struct oc_env {
+    ec_config cfg;
+    int N, H;
+    int64_t B;
+    double *rate, *tfr;
+    uint8_t* adj;
+    oc_one* envs;
+    int n_threads;
+};
+typedef struct oc_env* oc_handle;
+
+/* edge_node.py:159-166 + task.py:6-33 */
+static void node_generate_task(const ec_config* c, oc_node* n) {
+    n->has_new = 0;
+    long arrival = mt_binomial(&n->task_rng, 1, n->p);
+    if (arrival == 1) {
+        oc_task t;
+        memset(&t, 0, sizeof t);
+        t.id = mt_double(&n->task_rng);
+        t.size = mt_uniform(&n->task_rng, c->task_size_min, c->task_size_max) * 1024 * 8;
+        t.cycles = mt_uniform(&n->task_rng, c->task_complexity_min, c->task_complexity_max) * t.size;
+        t.deadline = c->deadline;
+        q_push(&n->buffer, &t);
+    }
+    if (n->buffer.len > 0) {
+        n->new_task = q_popleft(&n->buffer);
+        n->has_new = 1;
+    }
+}
+
+/* edge_node.py:199-234; returns -1 where the reference would raise ZeroDivisionError */
+static int node_offload(struct oc_env* E, oc_one* env, oc_node* n, int64_t action) {
+    const ec_config* c = &E->cfg;
+    n->completion_time = 0;
+    n->failure = n->drop = n->finish = n->success = 0;
+    n->reward = 0;
+    if (action == E->N || !n->has_new) return 0;
+    if (action < 0 || action > E->N) return -1;
+    oc_task* task = &n->new_task;
+    for (int i = 0; i < n->buffer.len; i++) n->buffer.v[i].bwt += c->mini_time_slot;
+    if (action == n->id) {
+        task->tt = 0;
+        task->et = task->cycles / n->cap;
+        task->efr = n->efr;
+        task->tfr = 0;
+        q_push(&n->execution, task);
+    } else {
+        double rate = E->rate[n->id * E->N + action];
+        if (rate == 0.0) return -1;
+        task->tt = task->size / rate;
+        task->tfr = E->tfr[n->id * E->N + action];
+        task->hop += 1;
+        q_push(&env->nodes[action].recv[n->id], task);
+    }
+    /* the reference leaves new_task referenced; it is overwritten by the next generate_task */
+    return 0;
+}
+
+static double task_time(const oc_task* t) { return t->ewt + t->cet + t->twt + t->ctt + t->bwt; }
+
+/* edge_node.py:236-309 */
+static void node_execute(const ec_config* c, oc_node* n, int H) {
+    if (n->execution.len > n->max_execution_len) n->max_execution_len = n->execution.len;
+    int temp_len = n->execution.len < c->k ? n->execution.len : c->k;
+    for (int i = 0; i < temp_len; i++) {
+        if (n->executing.len < c->k) {
+            oc_task t = q_popleft(&n->execution);
+            q_push(&n->executing, &t);
+        }
+    }
+    if (n->executing.len > n->max_executing_len) n->max_executing_len = n->executing.len;
+    int index = 0, index_drop = 0, len0 = n->executing.len;
+    for (int i = 0; i < n->execution.len; i++) n->execution.v[i].ewt += c->mini_time_slot;
+    while (n->executing.len > 0 && (index + index_drop) < len0) {
+        oc_task* t = &n->executing.v[index];
+        t->cet += c->mini_time_slot;
+        double tt = task_time(t);
+        double rel = exp(-t->efr * c->mini_time_slot);
+        int failure = mt_double(&n->fail_rng) > rel;
+        if (failure) {
+            n->reward += c->task_failure_penalty;
+            n->failure++;
+            n->finish++;
+            q_remove_at(&n->executing, index);
+            index_drop++;
+        } else if (tt > t->deadline) {
+            n->reward += c->task_drop_penalty;
+            n->drop++;
+            n->finish++;
+            n->completion_time += tt;
+            q_remove_at(&n->executing, index);
+            index_drop++;
+        } else if (t->cet >= t->et) {
+            n->reward += c->task_success_reward;
+            n->reward += (t->hop > 1) ? c->task_hop_penalty * (t->hop - 1) : 0;
+            n->success++;
+            n->finish++;
+            n->completion_time += tt;
+            n->hop_hist[t->hop < H ? t->hop : H - 1]++;
+            q_remove_at(&n->executing, index);
+            index_drop++;
+        } else {
+            index++;
+        }
+    }
+    int w = 0;
+    for (int i = 0; i < n->execution.len; i++) {
+        oc_task* t = &n->execution.v[i];
+        double tt = task_time(t);
+        if (tt > t->deadline) {
+            n->drop++;
+            n->finish++;
+            n->reward += c->task_drop_penalty;
+            n->completion_time += tt;
+        } else {
+            if (w != i) n->execution.v[w] = *t;
+            w++;
+        }
+    }
+    n->execution.len = w;
+}
+
+/* edge_node.py:311-333 */
+static void node_receive(const ec_config* c, oc_node* n, int N) {
+    for (int s = 0; s < N; s++) {
+        oc_q* q = &n->recv[s];
+        if (q->len == 0) continue;
+        oc_task* t = &q->v[0];
+        t->ctt += c->mini_time_slot;
+        for (int i = 1; i < q->len; i++) q->v[i].twt += c->mini_time_slot;
+        double rel = exp(-t->tfr * c->mini_time_slot);
+        int failure = mt_double(&n->fail_rng) > rel;
+        if (failure) {
+            n->failure++;
+            n->finish++;
+            n->reward += c->task_failure_penalty;
+            (void)q_popleft(q);
+        } else if (t->ctt >= t->tt) {
+            n->reward += (t->hop > 1) ? c->task_hop_penalty * (t->hop - 1) : 0;
+            oc_task moved = q_popleft(q);
+            q_push(&n->buffer, &moved);
+        }
+    }
+}
+
+static void node_reset(oc_node* n, int N) {
+    n->execution.len = 0;
+    for (int s = 0; s < N; s++) n->recv[s].len = 0;
+    n->buffer.len = 0;
+    n->has_new = 0;
+    n->executing.len = 0;
+}
+
+/* ---------------------------------------------------------------- batch API */
+const char* oc_version(void) { return "ec_oracle 1"; }
+
+int oc_create(const ec_config* cfg, const ec_topology* topo, int64_t n_envs, int64_t env_id_base, int n_threads,
+              oc_handle* out) {
+    struct oc_env* E = (struct oc_env*)calloc(1, sizeof *E);
+    E->cfg = *cfg;
+    int N = E->N = cfg->n_nodes;
+    E->H = cfg->hop_hist_len > 0 ? cfg->hop_hist_len : 32;
+    E->B = n_envs;
+    E->n_threads = n_threads > 0 ? n_threads : 1;
+    E->rate = (double*)malloc(sizeof(double) * N * N);
+    E->tfr = (double*)malloc(sizeof(double) * N * N);
+    E->adj = (uint8_t*)malloc((size_t)N * (N + 1));
+    memcpy(E->rate, topo->rate, sizeof(double) * N * N);
+    memcpy(E->tfr, topo->tfr, sizeof(double) * N * N);
+    memcpy(E->adj, topo->adj, (size_t)N * (N + 1));
+    E->envs = (oc_one*)calloc(n_envs, sizeof(oc_one));
+    for (int64_t e = 0; e < n_envs; e++) {
+        oc_one* env = &E->envs[e];
+        env->nodes = (oc_node*)calloc(N, sizeof(oc_node));
+        for (int i = 0; i < N; i++) {
+            oc_node* n = &env->nodes[i];
+            n->id = i;
+            n->cores = topo->cores[i];
+            n->cap = topo->cpu_capacity[i];
+            n->p = topo->task_p[i];
+            n->efr = topo->efr[i];
+            n->qlen = topo->queue_len[i];
+            /* parallel_episode_runner.py:19-20 + edge_node.py:28-29 */
+            mt_seed(&n->task_rng, (uint32_t)(cfg->task_seed + env_id_base + e + i));
+            mt_seed(&n->fail_rng, (uint32_t)(cfg->failure_seed + env_id_base + e + i));
+            n->recv = (oc_q*)calloc(N, sizeof(oc_q));
+            n->hop_hist = (long*)calloc(E->H, sizeof(long));
+        }
+        /* edge_computing_env.py:16-18 */
+        env->current_step = 0;
+        for (int i = 0; i < N; i++) node_generate_task(cfg, &env->nodes[i]);
+    }
+    *out = E;
+    return 0;
+}
+
+int oc_destroy(oc_handle E) {
+    for (int64_t e = 0; e < E->B; e++) {
+        for (int i = 0; i < E->N; i++) {
+            oc_node* n = &E->envs[e].nodes[i];
+            free(n->execution.v);
+            free(n->executing.v);
+            free(n->buffer.v);
+            for (int s = 0; s < E->N; s++) free(n->recv[s].v);
+            free(n->recv);
+            free(n->hop_hist);
+        }
+        free(E->envs[e].nodes);
+    }
+    free(E->envs);
+    free(E->rate);
+    free(E->tfr);
+    free(E->adj);
+    free(E);
+    return 0;
+}
+
+/* edge_computing_env.py:145-148 */
+int oc_reset(oc_handle E) {
+    for (int64_t e = 0; e < E->B; e++) {
+        E->envs[e].current_step = 0;
+        for (int i = 0; i < E->N; i++) node_reset(&E->envs[e].nodes[i], E->N);
+    }
+    return 0;
+}
+
+/* edge_node.py:109-136 / 179-197; obs is fp64 here (np.array of Python floats) */
+static void env_observe(struct oc_env* E, oc_one* env, double* obs, int32_t* avail) {
+    const ec_config* c = &E->cfg;
+    int N = E->N, A = N + 1;
+    for (int i = 0; i < N; i++) {
+        oc_node* n = &env->nodes[i];
+        if (obs) {
+            double* o = obs + 9 * i;
+            o[0] = n->efr / c->execution_failure_rate_max;
+            o[1] = n->cores / c->core_norm;
+            o[2] = n->p / c->task_probability_max;
+            o[3] = n->execution.len / n->qlen;
+            double w = 0;
+            for (int j = 0; j < n->execution.len; j++) w += n->execution.v[j].et - n->execution.v[j].cet;
+            o[4] = w / c->deadline;
+            if (n->has_new) {
+                double norm = c->task_size_max * 1024 * 8;
+                o[5] = n->new_task.size / norm;
+                o[6] = n->new_task.cycles / (c->task_complexity_max * c->task_size_max * 1024 * 8);
+                o[7] = n->new_task.deadline / c->deadline;
+                o[8] = n->new_task.hop;
+            } else {
+                o[5] = o[6] = o[7] = -1;
+                o[8] = 0;
+            }
+        }
+        if (avail) {
+            int32_t* a = avail + A * i;
+            if (n->has_new) {
+                int cnt = 0;
+                for (int j = 0; j < A; j++) a[j] = E->adj[i * A + j];
+                for (int j = 0; j < N; j++)
+                    if (env->nodes[j].execution.len >= env->nodes[j].qlen * c->rl_queue_coeff) a[j] = 0;
+                for (int j = 0; j < A; j++) cnt += a[j];
+                if (cnt == 0) a[i] = 1;
+            } else {
+                for (int j = 0; j < A; j++) a[j] = 0;
+                a[N] = 1;
+            }
+        }
+    }
+}
+
+int oc_observe(oc_handle E, double* obs, int32_t* avail) {
+    int N = E->N;
+#pragma omp parallel for num_threads(E->n_threads) schedule(static)
+    for (int64_t e = 0; e < E->B; e++)
+        env_observe(E, &E->envs[e], obs ? obs + e * N * 9 : NULL, avail ? avail + e * N * (N + 1) : NULL);
+    return 0;
+}
+
+/* edge_computing_env.py:84-143.  reward / completion_time are fp64 (Python floats).
+ * Returns the number of envs that hit the reference's ZeroDivisionError path. */
+int oc_step(oc_handle E, const int64_t* actions, double* reward, uint8_t* terminated, int32_t* counters,
+            double* completion_time, int32_t* hop_hist) {
+    const ec_config* c = &E->cfg;
+    int N = E->N, H = E->H;
+    int bad = 0;
+#pragma omp parallel for num_threads(E->n_threads) schedule(static) reduction(+ : bad)
+    for (int64_t e = 0; e < E->B; e++) {
+        oc_one* env = &E->envs[e];
+        for (int i = 0; i < N; i++)
+            if (node_offload(E, env, &env->nodes[i], actions[e * N + i]) != 0) bad++;
+        for (int s = 0; s < c->mini_slots; s++) {
+            for (int i = 0; i < N; i++) node_execute(c, &env->nodes[i], H);
+            for (int i = 0; i < N; i++) node_receive(c, &env->nodes[i], N);
+        }
+        double rew = 0, ct = 0;
+        long fail = 0, drop = 0, fin = 0, succ = 0;
+        for (int i = 0; i < N; i++) {
+            oc_node* n = &env->nodes[i];
+            rew += n->reward;
+            ct += n->completion_time;
+            fail += n->failure;
+            drop += n->drop;
+            fin += n->finish;
+            succ += n->success;
+        }
+        env->current_step += 1;
+        for (int i = 0; i < N; i++) node_generate_task(c, &env->nodes[i]);
+        if (reward) reward[e] = rew;
+        if (completion_time) completion_time[e] = ct;
+        if (counters) {
+            counters[4 * e + 0] = (int32_t)fin;
+            counters[4 * e + 1] = (int32_t)succ;
+            counters[4 * e + 2] = (int32_t)drop;
+            counters[4 * e + 3] = (int32_t)fail;
+        }
+        if (hop_hist) {
+            for (int h = 0; h < H; h++) {
+                long t = 0;
+                for (int i = 0; i < N; i++) t += env->nodes[i].hop_hist[h];
+                hop_hist[e * H + h] = (int32_t)t;
+            }
+        }
+        if (terminated) terminated[e] = env->current_step >= c->episode_limit;
+    }
+    return bad;
+}
+
+static long ticks_of(double x, double dt) { return lround(x / dt); }
+
+/* same row format as ec_debug_dump (include/marl_amd.h) */
+int oc_debug_dump(oc_handle E, int64_t e, double* rows, int64_t max_rows, int64_t* n_rows) {
+    oc_one* env = &E->envs[e];
+    double dt = E->cfg.mini_time_slot;
+    int64_t r = 0;
+#define PUT(NODE, QT, POS, T)                                   \
+    do {                                                        \
+        if (r < max_rows) {                                     \
+            double* o = rows + 11 * r;                          \
+            o[0] = (NODE);                                      \
+            o[1] = (QT);                                        \
+            o[2] = (POS);                                       \
+            o[3] = (T)->size;                                   \
+            o[4] = (T)->cycles;                                 \
+            o[5] = (T)->hop;                                    \
+            o[6] = (double)ticks_of((T)->ewt, dt);              \
+            o[7] = (double)ticks_of((T)->cet, dt);              \
+            o[8] = (double)ticks_of((T)->twt, dt);              \
+            o[9] = (double)ticks_of((T)->ctt, dt);              \
+            o[10] = (double)ticks_of((T)->bwt, dt);             \
+        }                                                       \
+        r++;                                                    \
+    } while (0)
+    for (int i = 0; i < E->N; i++) {
+        oc_node* n = &env->nodes[i];
+        if (n->has_new) PUT(i, 0, 0, &n->new_task);
+        for (int j = 0; j < n->buffer.len; j++) PUT(i, 1, j, &n->buffer.v[j]);
+        for (int j = 0; j < n->execution.len; j++) PUT(i, 2, j, &n->execution.v[j]);
+        for (int j = 0; j < n->executing.len; j++) PUT(i, 3, j, &n->executing.v[j]);
+        for (int s = 0; s < E->N; s++)
+            for (int j = 0; j < n->recv[s].len; j++) PUT(i, 4 + s, j, &n->recv[s].v[j]);
+    }
+#undef PUT
+    *n_rows = r;
+    return 0;
+}
+
+int oc_debug_rng_cursors(oc_handle E, uint64_t* cur) {
+    for (int64_t e = 0; e < E->B; e++)
+        for (int i = 0; i < E->N; i++) {
+            cur[(e * E->N + i) * 2 + 0] = E->envs[e].nodes[i].task_rng.consumed;
+            cur[(e * E->N + i) * 2 + 1] = E->envs[e].nodes[i].fail_rng.consumed;
+        }
+    return 0;
+}
+
+/* live tasks / env (L-bar of BASELINE.md section 3) */
+int64_t oc_live_tasks(oc_handle E) {
+    int64_t t = 0;
+    for (int64_t e = 0; e < E->B; e++)
+        for (int i = 0; i < E->N; i++) {
+            oc_node* n = &E->envs[e].nodes[i];
+            t += n->has_new + n->buffer.len + n->execution.len + n->executing.len;
+            for (int s = 0; s < E->N; s++) t += n->recv[s].len;
+        }
+    return t;
+}
+
+/* ---------------------------------------------------------------- GAE (utils/advantage_utils.py:4-9) */
+/* fp32, one rounding per torch op, in the reference's order:
+ *   delta = r + (gamma * nv) * m - v ;  adv = delta + ((gamma*lambda) * adv_next) * m        */
+int oc_gae(const float* r, const float* v, const float* nv, const float* m, float* adv, int64_t B, int64_t T,
+           int64_t N, float gamma, float gamma_lambda) {
+    for (int64_t b = 0; b < B; b++)
+        for (int64_t n = 0; n < N; n++) {
+            volatile float next = 0.0f;
+            for (int64_t t = T - 1; t >= 0; t--) {
+                int64_t i = (b * T + t) * N + n;
+                volatile float a = gamma * nv[i];
+                volatile float a2 = a * m[i];
+                volatile float a3 = r[i] + a2;
+                volatile float delta = a3 - v[i];
+                volatile float g = gamma_lambda * next;
+                volatile float g2 = g * m[i];
+                next = delta + g2;
+                adv[i] = next;
+            }
+        }
+    return 0;
+}

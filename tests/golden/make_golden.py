@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by IMPORTING the reference.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py env10      # one group
+
+Every fixture is data only: inputs (seeds, actions) and the outputs the
+reference produced for them.  Each group runs in a fresh interpreter because
+the reference caches its topology at class level (edge_node.py:19-20,87-91) and
+seeds stdlib ``random`` at import (network_graph.py:13).
+
+Groups
+  rng      RandomState stream prefixes (edge_node.py:28-29, task.py:10-12)
+  env10    default topology (N=10, task_size_max=6000): static tables + action replay
+  env40    scaled topology (N=40): static tables + short action replay
+  gae      utils/advantage_utils.py:4-9 on random inputs
+"""
+import argparse
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("MARL_REFERENCE", "/root/reference")
+
+
+# --------------------------------------------------------------------------
+def _ref_args(extra):
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from default_config import add_default_args
+    from envs.edge_computing.multihop.edge_computing_config import add_edge_computing_env_args
+    from rl.policy_gradient_rl.ppo.ppo_config import add_ppo_args
+    p = argparse.ArgumentParser(conflict_handler='resolve')
+    p = add_default_args(p)
+    p = add_edge_computing_env_args(p)
+    p = add_ppo_args(p)
+    return p.parse_args(extra)
+
+
+def _ticks(x):
+    """timers are sums of k additions of mini_time_slot: recover k."""
+    return int(round(x / 0.05))
+
+
+def _snapshot_rows(env, step_idx):
+    """One row per live task: [step,node,qtype,pos,size,cycles,hop,ewt,cet,twt,ctt,bwt]
+    qtype: 0 new_task, 1 buffer_queue, 2 execution_queue, 3 executing_queue, 4+src receiving_queues[src]."""
+    rows = []
+
+    def put(node, qtype, pos, t):
+        rows.append([step_idx, node, qtype, pos, t.task_size, t.task_cpu_cycle, t.hop,
+                     _ticks(t.execute_waiting_time), _ticks(t.current_execute_time),
+                     _ticks(t.transmission_waiting_time), _ticks(t.current_transmission_time),
+                     _ticks(t.buffer_waiting_time)])
+
+    for n in env.edge_nodes:
+        if n.new_task is not None:
+            put(n.id, 0, 0, n.new_task)
+        for j, t in enumerate(n.buffer_queue):
+            put(n.id, 1, j, t)
+        for j, t in enumerate(n.execution_queue):
+            put(n.id, 2, j, t)
+        for j, t in enumerate(n.executing_queue):
+            put(n.id, 3, j, t)
+        for s, q in enumerate(n.receiving_queues):
+            for j, t in enumerate(q):
+                put(n.id, 4 + s, j, t)
+    return rows
+
+
+def _policy(name, rng, env, avail):
+    """Deterministic test policies (ours, not the reference's)."""
+    import numpy as np
+    N = len(avail)
+    acts = np.zeros(N, dtype=np.int64)
+    for i in range(N):
+        a = np.asarray(avail[i])
+        node = env.edge_nodes[i]
+        if name == "random_valid":
+            idx = np.flatnonzero(a)
+            acts[i] = idx[rng.randint(len(idx))]
+        elif name == "local_first":
+            acts[i] = i if a[i] else int(np.flatnonzero(a)[0])
+        elif name == "max_forward":
+            if a[N]:
+                acts[i] = N
+            else:
+                nb = [j for j in np.flatnonzero(a) if j != i and j != N]
+                acts[i] = nb[(env.current_step + i) % len(nb)] if nb else i
+        elif name == "unmasked":
+            # ignores the queue-length mask (still adjacency-legal, so no ZeroDivisionError in
+            # edge_node.py:227) and sometimes idles with a pending task (edge_node.py:208-210)
+            u = rng.random_sample()
+            if u < 0.1:
+                acts[i] = N
+            else:
+                cand = list(node.actions)
+                acts[i] = cand[rng.randint(len(cand))]
+        else:
+            raise KeyError(name)
+    return acts
+
+
+def _replay(args, k, policy, episodes, snap_every, pol_seed):
+    """ParallelRunner semantics for env k (parallel_episode_runner.py:17-21,40-113)."""
+    import copy
+    import numpy as np
+    from envs.env_register import env_register
+    a = copy.deepcopy(args)
+    a.task_seed += k
+    a.failure_seed += k
+    env = env_register[a.env_name](a)
+    N = a.edge_node_num
+    rng = np.random.RandomState(pol_seed)
+    out = {key: [] for key in ("actions", "obs", "avail", "reward", "terminated", "info",
+                               "next_obs", "qlen", "hop_keys")}
+    snaps = []
+    hop_hist = []
+    gstep = 0
+    for ep in range(episodes):
+        env.reset()
+        while True:
+            obs = env.get_obs()
+            avail = env.get_avail_actions()
+            acts = _policy(policy, rng, env, avail)
+            reward, terminated, info = env.step(acts)
+            out["actions"].append(acts)
+            out["obs"].append(np.asarray(obs, dtype=np.float64))
+            out["avail"].append(np.asarray(avail, dtype=np.int32))
+            out["reward"].append(float(reward))
+            out["terminated"].append(bool(terminated))
+            out["info"].append([info["finish_task_number"], info["success_finish_task_number"],
+                                info["drop_task_number"], info["failure_task_number"],
+                                info["task_completion_time"]])
+            hh = np.zeros(64, dtype=np.int64)
+            for h, c in info["max_hop_dict"].items():
+                hh[h] += c
+            hop_hist.append(hh)
+            out["next_obs"].append(np.asarray(env.get_obs(), dtype=np.float64))
+            # queue lengths after the step: [node, (new_task, buffer, execution, executing, recv[0..N-1])]
+            ql = np.zeros((N, 4 + N), dtype=np.int32)
+            for n in env.edge_nodes:
+                ql[n.id, 0] = 0 if n.new_task is None else 1
+                ql[n.id, 1] = len(n.buffer_queue)
+                ql[n.id, 2] = len(n.execution_queue)
+                ql[n.id, 3] = len(n.executing_queue)
+                for s, q in enumerate(n.receiving_queues):
+                    ql[n.id, 4 + s] = len(q)
+            out["qlen"].append(ql)
+            if gstep % snap_every == snap_every - 1:
+                snaps.extend(_snapshot_rows(env, gstep))
+            gstep += 1
+            if terminated:
+                break
+    res = {
+        "actions": np.asarray(out["actions"], dtype=np.int64),
+        "obs": np.asarray(out["obs"]),
+        "avail": np.asarray(out["avail"]),
+        "reward": np.asarray(out["reward"], dtype=np.float64),
+        "terminated": np.asarray(out["terminated"], dtype=np.uint8),
+        "info": np.asarray(out["info"], dtype=np.float64),
+        "next_obs": np.asarray(out["next_obs"]),
+        "qlen": np.asarray(out["qlen"]),
+        "hop_hist": np.asarray(hop_hist, dtype=np.int64),
+        "snap": np.asarray(snaps, dtype=np.float64).reshape(-1, 12),
+    }
+    return res
+
+
+def _static_tables(args):
+    """Static per-node tables as the reference builds them (edge_node.py:22-85)."""
+    import numpy as np
+    from envs.env_register import env_register
+    import copy
+    env = env_register[args.env_name](copy.deepcopy(args))
+    N = args.edge_node_num
+    nodes = env.edge_nodes
+    adj = np.zeros((N, N + 1), dtype=np.uint8)
+    for n in nodes:
+        for a in n.actions:
+            adj[n.id, a] = 1
+    return {
+        "edges": np.asarray(env.get_edges(), dtype=np.int64),
+        "adj_order": np.asarray([n.actions + [-1] * (N + 1 - len(n.actions)) for n in nodes], dtype=np.int64),
+        "adj": adj,
+        "cores": np.asarray([int(n.cpu_core_num) for n in nodes], dtype=np.int64),
+        "p": np.asarray([n.task_probability for n in nodes], dtype=np.float64),
+        "efr": np.asarray([n.execution_failure_rate for n in nodes], dtype=np.float64),
+        "cap": np.asarray([float(n.cpu_capacity) for n in nodes], dtype=np.float64),
+        "qlen_max": np.asarray([n.execution_queue_len for n in nodes], dtype=np.float64),
+        "rate": np.asarray([n.transmission_rates for n in nodes], dtype=np.float64),
+        "tfr": np.asarray([n.transmission_failure_rates for n in nodes], dtype=np.float64),
+    }
+
+
+# --------------------------------------------------------------------------
+def gen_rng():
+    import numpy as np
+    out = {}
+    seeds = [0, 1, 100, 109, 200, 500, 601, 4295, 2 ** 32 - 1]
+    out["seeds"] = np.asarray(seeds, dtype=np.int64)
+    out["doubles"] = np.stack([np.random.RandomState(s).random_sample(1500) for s in seeds])
+    # generate_task draw pattern (edge_node.py:159-166 + task.py:10-12): binomial(1,p) then 3 doubles on arrival
+    ps = [0.0, 0.07474158005205533, 0.5, 0.5592089368350069, 0.9174961169661047, 1.0]
+    rows = []
+    for s in (100, 4195):
+        for p in ps:
+            r = np.random.RandomState(s)
+            for _ in range(300):
+                arr = r.binomial(1, p)
+                if arr == 1:
+                    tid = r.random()
+                    size = r.uniform(1000, 6000) * 1024 * 8
+                    cyc = r.uniform(800, 2400) * size
+                else:
+                    tid = size = cyc = -1.0
+                rows.append([s, p, arr, tid, size, cyc])
+    out["task_draws"] = np.asarray(rows, dtype=np.float64)
+    # node-parameter stream (edge_node.py:31-34,57): choice, uniform, uniform per node
+    r = np.random.RandomState(500)
+    rows = []
+    for _ in range(40):
+        c = r.choice([4, 8, 12, 16, 20, 24, 28, 32])
+        rows.append([c, r.uniform(0, 1.0), r.uniform(0, 0.3)])
+    out["node_param_draws"] = np.asarray(rows, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "rng.npz"), **out)
+
+
+def gen_env(tag):
+    import numpy as np
+    if tag == "env10":
+        args = _ref_args(["--task_size_max=6000", "--seed=100"])
+        cases = [(0, "random_valid", 3), (1, "random_valid", 3), (2, "random_valid", 2), (7, "random_valid", 2),
+                 (4095, "random_valid", 2), (0, "local_first", 2), (3, "local_first", 2),
+                 (0, "max_forward", 2), (5, "max_forward", 2), (0, "unmasked", 2), (11, "unmasked", 2)]
+    elif tag == "env10d":
+        # reference defaults (task_size_max=2000, edge_computing_config.py:14)
+        args = _ref_args(["--seed=100"])
+        cases = [(0, "random_valid", 2), (9, "unmasked", 2)]
+    elif tag == "env40":
+        args = _ref_args(["--task_size_max=6000", "--seed=100", "--edge_node_num=40"])
+        cases = [(0, "random_valid", 2), (16383, "random_valid", 1), (3, "max_forward", 1), (8, "unmasked", 1)]
+    else:
+        raise KeyError(tag)
+    out = {}
+    cfg_keys = ["episode_limit", "mini_time_slot", "mini_time_slot_num", "edge_node_num", "task_probability_min",
+                "task_probability_max", "task_size_min", "task_size_max", "task_complexity_min",
+                "task_complexity_max", "deadline", "single_core_cpu_capacity", "transmission_rate_min",
+                "transmission_rate_max", "execution_failure_rate_min", "execution_failure_rate_max",
+                "transmission_failure_rate_min", "transmission_failure_rate_max", "task_drop_penalty",
+                "task_failure_penalty", "task_success_reward", "task_hop_penalty", "edge_node_seed", "task_seed",
+                "failure_seed", "rl_queue_coeff", "link_seed", "k", "beta"]
+    out["cfg_keys"] = np.asarray(cfg_keys)
+    out["cfg_vals"] = np.asarray([float(getattr(args, k)) for k in cfg_keys], dtype=np.float64)
+    out["cpu_core_list"] = np.asarray(args.cpu_core_list, dtype=np.int64)
+    # NOTE: the topology is generated by the FIRST env constructed in the process
+    for k, v in _static_tables(args).items():
+        out["static_" + k] = v
+    names = []
+    for ci, (k, pol, eps) in enumerate(cases):
+        res = _replay(args, k, pol, eps, snap_every=10, pol_seed=1234 + ci)
+        name = "c%02d" % ci
+        names.append("%s:%d:%s:%d" % (name, k, pol, eps))
+        for kk, vv in res.items():
+            if kk in ("obs", "next_obs"):
+                pass
+            out[name + "_" + kk] = vv
+    out["cases"] = np.asarray(names)
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+
+
+def gen_gae():
+    import numpy as np
+    import torch as th
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from utils.advantage_utils import get_gae
+    out = {}
+    for name, (B, T, N) in {"a": (8, 100, 10), "b": (3, 17, 5)}.items():
+        g = th.Generator().manual_seed(7 + B)
+        ns = argparse.Namespace(n_threads=B, episode_limit=T, n_agents=N, gamma=0.99, lambda_=0.95, device="cpu")
+        r = th.randn(B, T, N, 1, generator=g)
+        v = th.randn(B, T, N, 1, generator=g)
+        nv = th.randn(B, T, N, 1, generator=g)
+        m = (th.rand(B, T, N, 1, generator=g) > 0.1).float()
+        m[:, -1] = 0
+        adv = get_gae(ns, r, v, nv, m)
+        for k, t in dict(r=r, v=v, nv=nv, m=m, adv=adv).items():
+            out["%s_%s" % (name, k)] = t.numpy()
+    np.savez_compressed(os.path.join(HERE, "gae.npz"), **out)
+
+
+GROUPS = {"rng": gen_rng, "env10": lambda: gen_env("env10"), "env10d": lambda: gen_env("env10d"),
+          "env40": lambda: gen_env("env40"), "gae": gen_gae}
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        GROUPS[sys.argv[1]]()
+    else:
+        for g in GROUPS:
+            print("generating", g, flush=True)
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), g])
