@@ -1,0 +1,224 @@
+"""The edge_computing environment on the HIP library.
+
+`BatchedEdgeComputingEnv`  B = args.n_threads environments stepped by one kernel launch; every output is
+                           a device tensor.  Env e of the batch is the reference env that
+                           ParallelRunner builds for worker (ec_env_id_base + e)
+                           (runners/parallel_episode_runner.py:17-21): seeds task_seed+e, failure_seed+e.
+`EdgeComputingEnv`         the reference's single-env contract (envs/edge_computing/multihop/
+                           edge_computing_env.py:7-160): Python float reward, bool terminated, info dict,
+                           numpy observations — a batch of one.
+
+State lives in HBM inside the library handle; this file only owns output tensors and the handle.
+"""
+import ctypes as C
+
+import numpy as np
+import torch as th
+
+from marl_amd import _abi
+from marl_amd.envs.edge_computing.multihop.network_graph import get_static_tables
+from marl_amd.envs.multiagentenv import MultiAgentEnv
+
+OBS_SHAPE = 9  # edge_node.py:74
+
+INFO_KEYS = ("finish_task_number", "success_finish_task_number", "drop_task_number", "failure_task_number")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedEdgeComputingEnv(MultiAgentEnv):
+    def __init__(self, args, n_envs=None, env_id_base=None, device=None):
+        if not th.cuda.is_available():
+            raise RuntimeError("BatchedEdgeComputingEnv needs a ROCm device: marl_amd has no CPU fallback")
+        self.lib = _abi.lib()
+        self.n_envs = int(n_envs if n_envs is not None else getattr(args, "n_threads", 1))
+        self.env_id_base = int(env_id_base if env_id_base is not None else getattr(args, "ec_env_id_base", 0))
+        self.device = th.device(device if device is not None else "cuda:%d" % th.cuda.current_device())
+        self.tables = get_static_tables(args)
+        self.hop_hist_len = int(getattr(args, "ec_hop_hist_len", 32))
+        self.cfg = _abi.config_from_args(args, hop_hist_len=self.hop_hist_len)
+        topo, self._keep = _abi.topology_from_tables(self.tables)
+        self._h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else th.cuda.current_device()
+        _abi.check(self.lib.ec_create(C.byref(self.cfg), C.byref(topo), self.n_envs, self.env_id_base, dev_index,
+                                      C.byref(self._h)), "ec_create")
+
+        # edge_computing_env.py:24-30
+        args.n_actions = args.edge_node_num + 1
+        args.n_agents = args.edge_node_num
+        self.args = args
+        self.n_agents = args.edge_node_num
+        self.n_actions = args.edge_node_num + 1
+        self.episode_limit = args.episode_limit
+        self.obs_shape = OBS_SHAPE
+        self.state_shape = OBS_SHAPE * self.n_agents
+
+        B, N, A = self.n_envs, self.n_agents, self.n_actions
+        dev = self.device
+        self.obs = th.empty(B, N, OBS_SHAPE, dtype=th.float32, device=dev)
+        self.avail = th.empty(B, N, A, dtype=th.int32, device=dev)
+        self.reward = th.empty(B, dtype=th.float32, device=dev)
+        self.terminated = th.empty(B, dtype=th.uint8, device=dev)
+        self.counters = th.empty(B, 4, dtype=th.int32, device=dev)
+        self.completion_time = th.empty(B, dtype=th.float32, device=dev)
+        self.hop_hist = th.zeros(B, self.hop_hist_len, dtype=th.int32, device=dev)
+        self._obs_valid = False
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ec_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(th.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ batched API (device tensors)
+    def reset(self):
+        _abi.check(self.lib.ec_reset(self._h, self._stream()), "ec_reset")
+        self._obs_valid = False
+
+    def observe(self, obs=None, avail=None):
+        """Fill (and return) obs [B,N,9] f32 and avail [B,N,A] i32 for the current state."""
+        obs = self.obs if obs is None else obs
+        avail = self.avail if avail is None else avail
+        _abi.check(self.lib.ec_observe(self._h, _ptr(obs), _ptr(avail), self._stream()), "ec_observe")
+        if obs is self.obs and avail is self.avail:
+            self._obs_valid = True
+        return obs, avail
+
+    def get_obs(self):
+        if not self._obs_valid:
+            self.observe()
+        return self.obs
+
+    def get_avail_actions(self):
+        if not self._obs_valid:
+            self.observe()
+        return self.avail
+
+    def step(self, actions, want_hops=False, fuse_observe=True):
+        """actions: int64 [B,N] device tensor.  Returns (reward[B] f32, terminated[B] u8, info) where info holds
+        device tensors: the four counters of edge_computing_env.py:130-135 as columns of `counters`,
+        `task_completion_time`, and (if want_hops) the cumulative `max_hop_dict` histogram.  With
+        fuse_observe the post-step observation lands in self.obs / self.avail in the same launch."""
+        if actions.dtype != th.int64 or not actions.is_contiguous() or actions.device != self.device:
+            actions = actions.to(device=self.device, dtype=th.int64).contiguous()
+        if actions.numel() != self.n_envs * self.n_agents:
+            raise ValueError("actions must have %d x %d elements" % (self.n_envs, self.n_agents))
+        _abi.check(self.lib.ec_step(self._h, _ptr(actions), _ptr(self.reward), _ptr(self.terminated),
+                                    _ptr(self.counters), _ptr(self.completion_time),
+                                    _ptr(self.hop_hist) if want_hops else None,
+                                    _ptr(self.obs) if fuse_observe else None,
+                                    _ptr(self.avail) if fuse_observe else None, self._stream()), "ec_step")
+        self._obs_valid = bool(fuse_observe)
+        info = {"counters": self.counters, "task_completion_time": self.completion_time}
+        if want_hops:
+            info["hop_hist"] = self.hop_hist
+        return self.reward, self.terminated, info
+
+    def random_actions(self, seed, counter, out=None):
+        """Uniform over the current availability mask (config 2 of BASELINE.json)."""
+        avail = self.get_avail_actions()
+        out = out if out is not None else th.empty(self.n_envs, self.n_agents, dtype=th.int64, device=self.device)
+        _abi.check(self.lib.ec_random_policy(_ptr(avail), self.n_envs * self.n_agents, self.n_actions, int(seed),
+                                             int(counter), _ptr(out), self._stream()), "ec_random_policy")
+        return out
+
+    def status(self, clear=True):
+        st = C.c_uint32(0)
+        _abi.check(self.lib.ec_status(self._h, C.byref(st), int(clear), self._stream()), "ec_status")
+        return st.value
+
+    def check_status(self):
+        """Raise what the reference would have raised (or report a capacity overflow)."""
+        st = self.status()
+        if st & _abi.EC_ST_BAD_ACTION:
+            raise ZeroDivisionError("float division by zero (action targets a non-adjacent node, edge_node.py:227)")
+        if st & ~_abi.EC_ST_HOP_OVERFLOW:
+            raise _abi.EcError("device status 0x%x: queue/tick capacity exceeded (raise --ec_cap_* / --ec_max_ticks)" % st)
+        return st
+
+    def info_geometry(self):
+        v = (C.c_int64 * 12)()
+        _abi.check(self.lib.ec_info(self._h, v, 12), "ec_info")
+        keys = ("B", "N", "k", "D", "cap_buffer", "cap_recv", "cap_wait", "max_ticks", "threads_per_block",
+                "envs_per_block")
+        out = {k: int(v[i]) for i, k in enumerate(keys)}
+        out["state_bytes"] = int(v[10]) | (int(v[11]) << 32)
+        return out
+
+    def debug_dump(self, env, max_rows=8192):
+        rows = np.empty((max_rows, 11), dtype=np.float64)
+        n = C.c_int64()
+        _abi.check(self.lib.ec_debug_dump(self._h, int(env), rows.ctypes.data_as(C.c_void_p), max_rows, C.byref(n)),
+                   "ec_debug_dump")
+        if n.value > max_rows:
+            return self.debug_dump(env, max_rows=int(n.value))
+        return rows[: n.value].copy()
+
+    def debug_rng_cursors(self):
+        cur = np.empty((self.n_envs, self.n_agents, 2), dtype=np.uint64)
+        _abi.check(self.lib.ec_debug_rng_cursors(self._h, cur.ctypes.data_as(C.c_void_p)), "ec_debug_rng_cursors")
+        return cur
+
+    # ------------------------------------------------------------------ shape queries (multiagentenv.py)
+    def get_obs_size(self):
+        return self.obs_shape
+
+    def get_state_size(self):
+        return self.state_shape
+
+    def get_total_actions(self):
+        return self.n_actions
+
+    def get_state(self):
+        return self.get_obs().reshape(self.n_envs, -1)
+
+    def get_edges(self):
+        return np.array(self.tables.unique_edges())
+
+    def get_env_info(self):
+        return {"state_shape": self.state_shape, "obs_shape": self.obs_shape, "n_actions": self.n_actions,
+                "n_agents": self.n_agents, "episode_limit": self.episode_limit}
+
+
+class EdgeComputingEnv(BatchedEdgeComputingEnv):
+    """A batch of one with the reference's Python-level return types."""
+
+    def __init__(self, args):
+        super().__init__(args, n_envs=1, env_id_base=getattr(args, "ec_env_id_base", 0))
+
+    def get_obs(self):
+        return super().get_obs()[0].double().cpu().numpy()
+
+    def get_obs_agent(self, agent_id):
+        return self.get_obs()[agent_id]
+
+    def get_state(self):
+        return self.get_obs().reshape(-1)
+
+    def get_avail_actions(self):
+        return super().get_avail_actions()[0].cpu().tolist()
+
+    def get_avail_agent_actions(self, agent_id):
+        return self.get_avail_actions()[agent_id]
+
+    def step(self, actions):
+        a = th.as_tensor(np.asarray(actions), dtype=th.int64, device=self.device).reshape(1, self.n_agents)
+        super().step(a, want_hops=True)
+        self.check_status()
+        c = self.counters[0].cpu().tolist()
+        hops = self.hop_hist[0].cpu().tolist()
+        info = {k: int(v) for k, v in zip(INFO_KEYS, c)}
+        info["task_completion_time"] = float(self.completion_time[0])
+        info["max_hop_dict"] = {h: n for h, n in enumerate(hops) if n}
+        return float(self.reward[0]), bool(self.terminated[0]), info

@@ -1,0 +1,204 @@
+"""Parity of the HIP environment (through the C ABI) with the reference:
+  * action replay of the golden trajectories captured from the reference (tests/golden/*.npz)
+  * lock-step comparison with the CPU oracle on batches, driven by on-device policies
+Bit-exact for every integer output (availability, counters, termination, hop histogram, queue
+contents, tick counters, RNG cursors); reward / completion time / observations are the fp32
+rounding of the reference's fp64 value and are compared bit-for-bit with that rounding."""
+import numpy as np
+import pytest
+
+from tests.util import args_from_golden, golden_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _th():
+    import torch as th
+    return th
+
+
+def _compare_dump(gpu_rows, ref_rows, cap, tag):
+    """rows: [node,qtype,pos,size,cycles,hop,ewt,cet,twt,ctt,bwt]; see include/marl_amd.h ec_debug_dump"""
+    assert gpu_rows.shape == ref_rows.shape, (tag, gpu_rows.shape, ref_rows.shape)
+    if not len(ref_rows):
+        return
+    assert np.array_equal(gpu_rows[:, :3], ref_rows[:, :3]), (tag, "queue layout")
+    assert np.array_equal(gpu_rows[:, 5:], ref_rows[:, 5:]), (tag, "hop / tick counters")
+    qt = ref_rows[:, 1]
+    moving = (qt < 2) | (qt >= 4)
+    assert np.array_equal(gpu_rows[moving, 3:5], ref_rows[moving, 3:5]), (tag, "size / cycles")
+    waiting = qt == 2
+    et = ref_rows[waiting, 4] / cap[ref_rows[waiting, 0].astype(int)]
+    assert np.array_equal(gpu_rows[waiting, 3], et), (tag, "execute_time")
+
+
+def _make_env(args, n_envs, base):
+    from marl_amd.envs.edge_computing.multihop.edge_computing_env import BatchedEdgeComputingEnv
+    args.ec_hop_hist_len = 64
+    return BatchedEdgeComputingEnv(args, n_envs=n_envs, env_id_base=base)
+
+
+@pytest.mark.parametrize("name", ["env10", "env10d", "env40"])
+def test_golden_action_replay(name):
+    th = _th()
+    g = load_golden(name)
+    args = args_from_golden(g)
+    for case, k, pol, eps in golden_cases(g):
+        env = _make_env(args, 1, k)
+        cap = env.tables.cap
+        actions = g[case + "_actions"]
+        snap = g[case + "_snap"]
+        N = args.edge_node_num
+        for t in range(actions.shape[0]):
+            tag = (name, case, pol, t)
+            if t % args.episode_limit == 0:
+                env.reset()
+            obs, avail = env.observe()
+            assert np.array_equal(obs[0].cpu().numpy(), g[case + "_obs"][t].astype(np.float32)), (tag, "obs")
+            assert np.array_equal(avail[0].cpu().numpy(), g[case + "_avail"][t]), (tag, "avail")
+            a = th.as_tensor(actions[t], device=env.device).reshape(1, N)
+            reward, term, info = env.step(a, want_hops=True)
+            gi = g[case + "_info"][t]
+            assert reward[0].item() == np.float32(g[case + "_reward"][t]), (tag, "reward")
+            assert int(term[0]) == int(g[case + "_terminated"][t]), (tag, "terminated")
+            assert np.array_equal(info["counters"][0].cpu().numpy(), gi[:4].astype(np.int32)), (tag, "counters")
+            assert info["task_completion_time"][0].item() == np.float32(gi[4]), (tag, "completion")
+            assert np.array_equal(info["hop_hist"][0].cpu().numpy(), g[case + "_hop_hist"][t]), (tag, "hops")
+            # fused post-step observation
+            assert np.array_equal(env.obs[0].cpu().numpy(), g[case + "_next_obs"][t].astype(np.float32)), (tag, "next_obs")
+            want = snap[snap[:, 0] == t][:, 1:]
+            if t % 10 == 9:
+                rows = env.debug_dump(0)
+                ql = np.zeros((N, 4 + N), dtype=np.int32)
+                for r in rows:
+                    ql[int(r[0]), int(r[1])] += 1
+                assert np.array_equal(ql, g[case + "_qlen"][t]), (tag, "qlen")
+                _compare_dump(rows, want, cap, tag)
+        assert env.status() == 0
+        env.close()
+
+
+def _lockstep(args, B, base, steps, policy, oracle_lib, dump_envs=(0,), check_every=1):
+    """GPU batch vs oracle batch under the same actions."""
+    th = _th()
+    from marl_amd._abi import config_from_args
+    env = _make_env(args, B, base)
+    cfg = config_from_args(args, hop_hist_len=64)
+    ora = oracle_lib.OracleEnv(cfg, env.tables, B, env_id_base=base, n_threads=8)
+    N = args.edge_node_num
+    rng = np.random.RandomState(99)
+    nbr_lists = [nb + [i] for i, nb in enumerate(env.tables.neighbours)]
+    for t in range(steps):
+        if t % args.episode_limit == 0:
+            env.reset()
+            ora.reset()
+        obs, avail = env.observe()
+        if t % check_every == 0:
+            o_obs, o_avail = ora.observe()
+            assert np.array_equal(avail.cpu().numpy(), o_avail), (t, "avail")
+            assert np.array_equal(obs.cpu().numpy(), o_obs.astype(np.float32)), (t, "obs")
+        if policy == "random_valid":
+            a = env.random_actions(seed=5, counter=t)
+        elif policy == "unmasked":
+            # adjacency-legal but ignores the queue mask; sometimes idles with a pending task
+            pick = rng.randint(0, 1 << 30, size=(B, N))
+            a_np = np.empty((B, N), dtype=np.int64)
+            for i in range(N):
+                lst = np.asarray(nbr_lists[i] + [N])
+                a_np[:, i] = lst[pick[:, i] % len(lst)]
+            a = th.as_tensor(a_np, device=env.device)
+        else:
+            raise KeyError(policy)
+        reward, term, info = env.step(a, want_hops=(t % check_every == 0))
+        out = ora.step(a.cpu().numpy())
+        assert out["bad"] == 0
+        if t % check_every == 0:
+            assert np.array_equal(reward.cpu().numpy(), out["reward"].astype(np.float32)), (t, "reward")
+            assert np.array_equal(term.cpu().numpy(), out["terminated"]), (t, "terminated")
+            assert np.array_equal(info["counters"].cpu().numpy(), out["counters"]), (t, "counters")
+            assert np.array_equal(info["task_completion_time"].cpu().numpy(),
+                                  out["completion_time"].astype(np.float32)), (t, "completion")
+            assert np.array_equal(info["hop_hist"].cpu().numpy(), out["hop_hist"]), (t, "hops")
+            for e in dump_envs:
+                _compare_dump(env.debug_dump(e), ora.dump(e), env.tables.cap, (t, e))
+    assert np.array_equal(env.debug_rng_cursors(), ora.rng_cursors()), "rng cursors"
+    assert env.status() == 0
+    env.close()
+    ora.close()
+
+
+def test_lockstep_batch_random_valid(oracle_lib):
+    g = load_golden("env10")
+    _lockstep(args_from_golden(g), 70, 0, 250, "random_valid", oracle_lib, dump_envs=(0, 33, 69))
+
+
+def test_lockstep_batch_unmasked(oracle_lib):
+    g = load_golden("env10")
+    _lockstep(args_from_golden(g), 33, 4000, 200, "unmasked", oracle_lib, dump_envs=(0, 32))
+
+
+def test_lockstep_default_sizes(oracle_lib):
+    g = load_golden("env10d")
+    _lockstep(args_from_golden(g), 64, 7, 120, "random_valid", oracle_lib)
+
+
+def test_lockstep_n40(oracle_lib):
+    g = load_golden("env40")
+    _lockstep(args_from_golden(g), 50, 100, 150, "random_valid", oracle_lib, dump_envs=(0, 49))
+    _lockstep(args_from_golden(g), 7, 0, 110, "unmasked", oracle_lib, dump_envs=(3,))
+
+
+def test_lockstep_full_size_4096(oracle_lib):
+    """BASELINE.json config 2 size: 4096 envs x 10 agents, one full episode + reset, every output checked."""
+    g = load_golden("env10")
+    _lockstep(args_from_golden(g), 4096, 0, 130, "random_valid", oracle_lib, dump_envs=(0, 2047, 4095),
+              check_every=1)
+
+
+def test_bad_action_sets_status():
+    th = _th()
+    from marl_amd import _abi
+    g = load_golden("env10")
+    args = args_from_golden(g)
+    env = _make_env(args, 4, 0)
+    env.reset()
+    N = args.edge_node_num
+    idle = th.full((4, N), N, dtype=th.int64, device=env.device)
+    for _ in range(3):
+        env.step(idle)
+    assert env.status() == 0
+    # node 0 is adjacent to 1 and 9 only: 5 is the reference's ZeroDivisionError path
+    bad = idle.clone()
+    has_task = env.get_avail_actions()[:, 0, N] == 0
+    assert bool(has_task.any())
+    bad[:, 0] = 5
+    env.step(bad)
+    assert env.status(clear=False) & _abi.EC_ST_BAD_ACTION
+    with pytest.raises(ZeroDivisionError):
+        env.check_status()
+    env.close()
+
+
+def test_single_env_reference_contract():
+    """EdgeComputingEnv keeps the reference's Python-level return types."""
+    from marl_amd.envs.env_register import env_register
+    g = load_golden("env10")
+    args = args_from_golden(g)
+    env = env_register["edge_computing"](args)
+    assert env.get_env_info() == {"state_shape": 90, "obs_shape": 9, "n_actions": 11, "n_agents": 10,
+                                  "episode_limit": 100}
+    assert np.array_equal(env.get_edges(), g["static_edges"])
+    env.reset()
+    case = golden_cases(g)[0][0]
+    for t in range(20):
+        obs = env.get_obs()
+        avail = env.get_avail_actions()
+        assert isinstance(obs, np.ndarray) and obs.shape == (10, 9)
+        assert avail == g[case + "_avail"][t].tolist()
+        reward, terminated, info = env.step(g[case + "_actions"][t])
+        assert isinstance(reward, float) and isinstance(terminated, bool)
+        assert reward == float(np.float32(g[case + "_reward"][t]))
+        assert info["finish_task_number"] == int(g[case + "_info"][t][0])
+        assert set(info) == {"finish_task_number", "success_finish_task_number", "drop_task_number",
+                             "failure_task_number", "task_completion_time", "max_hop_dict"}
+    env.close()
