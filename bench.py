@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's headline metric on MI355X.
+
+Workload (BASELINE.json configs[1]): the batched edge_computing environment, 4096 envs x 10 agents per
+GPU, task_size_max=6000, uniform-random policy over the availability mask.  One "step" = one pass of
+the rollout hot path over the whole batch: random-policy kernel -> ec_step (offload, 10 mini-slots of
+execute/receive, statistics, generate_task) with the next observation + availability mask fused into the
+same launch; every episode_limit steps the envs are reset as ParallelRunner does.  Inputs and all state
+are resident in HBM; nothing crosses PCIe inside the timed region.
+
+    python bench.py --gpus 1 --steps 1000 --warmup 200
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Multi-GPU: environments are independent, so rank r owns env ids
+[r*B, (r+1)*B) (same seeds as a single 8*B batch) and there is no data-path collective: weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=1000)
+    p.add_argument("--warmup", type=int, default=200)
+    p.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    p.add_argument("--nodes", type=int, default=10, help="edge_node_num")
+    p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
+    p.add_argument("--roofline-steps", type=int, default=200)
+    p.add_argument("--threads", type=int, default=0, help="override threads per block of the step kernel")
+    return p.parse_args()
+
+
+class Rollout:
+    """The hot path of ParallelRunner.run (parallel_episode_runner.py:32-113) on device tensors."""
+
+    def __init__(self, env, use_graph):
+        import torch as th
+        self.th = th
+        self.env = env
+        self.T = env.episode_limit
+        self.actions = th.empty(env.n_envs, env.n_agents, dtype=th.int64, device=env.device)
+        self.counter_dev = th.zeros(2, dtype=th.int64, device=env.device)
+        self.graph = None
+        self.steps_done = 0
+        if use_graph:
+            # warm the kernels on a side stream, then capture one whole episode
+            s = th.cuda.Stream(device=env.device)
+            s.wait_stream(th.cuda.current_stream(env.device))
+            with th.cuda.stream(s):
+                self._episode(3)
+            th.cuda.current_stream(env.device).wait_stream(s)
+            th.cuda.synchronize(env.device)
+            self.graph = th.cuda.CUDAGraph()
+            with th.cuda.graph(self.graph):
+                self._episode(self.T)
+
+    def _one_step(self):
+        self.env.random_actions(seed=0, counter=0, out=self.actions, counter_dev=self.counter_dev)
+        self.env.step(self.actions, fuse_observe=True)
+
+    def _episode(self, n):
+        self.env.reset()
+        self.env.observe()
+        for _ in range(n):
+            self._one_step()
+
+    def run(self, n_steps):
+        """Run exactly n_steps env steps (whole episodes first, then a partial one)."""
+        full, rem = divmod(n_steps, self.T)
+        for _ in range(full):
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._episode(self.T)
+        if rem:
+            self._episode(rem)
+        self.steps_done += n_steps
+
+
+def algorithmic_bytes_per_env_step(N, live, draws):
+    """I/O (actions, obs, avail, reward, counters/time, terminated) + 16 B/node header
+    read+write + 40 B canonical task record read+write per live task + 16 B per consumed MT19937 double."""
+    io = 4 * N + 36 * N + 4 * N * (N + 1) + 4 + 20 + 1
+    return io + 2 * 16 * N + 2 * 40 * live + 16 * draws
+
+
+def measure_roofline(env, roll, n_steps):
+    """Average ec_step kernel duration from HIP events recorded on the launch stream around each launch,
+    plus the measured L-bar (live tasks/env) and D-bar (MT19937 doubles/env-step) of the same steps."""
+    import torch as th
+    th.cuda.synchronize(env.device)
+    cur0 = env.debug_rng_cursors().astype("float64").sum()
+    live = []
+    pairs = []
+    env.reset()
+    env.observe()
+    for t in range(n_steps):
+        if t and t % env.episode_limit == 0:
+            env.reset()
+            env.observe()
+        env.random_actions(seed=0, counter=0, out=roll.actions, counter_dev=roll.counter_dev)
+        a, b = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+        a.record()
+        env.step(roll.actions, fuse_observe=True)
+        b.record()
+        pairs.append((a, b))
+        if t % 10 == 5:
+            live.append(env.live_tasks() / env.n_envs)
+    th.cuda.synchronize(env.device)
+    ms = sorted(a.elapsed_time(b) for a, b in pairs)
+    avg_ms = sum(ms) / len(ms)
+    cur1 = env.debug_rng_cursors().astype("float64").sum()
+    draws = (cur1 - cur0) / 2.0 / (n_steps * env.n_envs)
+    lbar = sum(live) / max(1, len(live))
+    return avg_ms, ms[len(ms) // 2], lbar, draws
+
+
+def cpu_baseline(args_ns, tables, n_envs, budget_s):
+    """The CPU oracle (a C port of the reference env) doing the same rollout work on the host cores."""
+    from marl_amd._abi import config_from_args
+    from oracle import ec_oracle
+    threads = max(1, min(16, os.cpu_count() or 1))
+    ora = ec_oracle.OracleEnv(config_from_args(args_ns), tables, n_envs, n_threads=threads)
+    T = args_ns.episode_limit
+    ora.rollout_random(T)  # warm-up episode
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        ora.rollout_random(T, seed=steps)
+        steps += T
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or steps >= 50 * T:
+            break
+    ora.close()
+    return {"value": n_envs * args_ns.edge_node_num * steps / dt, "unit": "agent-steps/s", "cores": threads,
+            "kind": "port",
+            "sample": "%d envs x %d steps (observe + random policy + step), OpenMP C oracle, %.1f s" % (n_envs, steps, dt)}
+
+
+def main():
+    a = parse()
+    import torch as th
+    import torch.distributed as dist
+    from marl_amd.envs.edge_computing.multihop.edge_computing_env import BatchedEdgeComputingEnv
+    from tests.util import make_args
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (a.gpus, world))
+    th.cuda.set_device(local)
+    dev = th.device("cuda:%d" % local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    if a.threads:
+        os.environ["MARL_AMD_EC_THREADS"] = str(a.threads)
+
+    ns = make_args(["--task_size_max=6000", "--seed=100", "--edge_node_num=%d" % a.nodes])
+    B, N = a.envs, a.nodes
+    env = BatchedEdgeComputingEnv(ns, n_envs=B, env_id_base=rank * B, device=dev)
+    roll = Rollout(env, use_graph=not a.no_graph)
+
+    def fence():
+        th.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            th.cuda.synchronize(dev)
+
+    roll.run(a.warmup)
+    fence()
+    t0 = time.perf_counter()
+    roll.run(a.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = th.tensor([dt], dtype=th.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = env.status()
+    if st & ~32:
+        raise SystemExit("device status 0x%x after the timed region" % st)
+
+    out = None
+    if rank == 0:
+        value = world * B * N * a.steps / dt
+        out = {
+            "metric": "env agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64/u32", "data": "synthetic",
+            "config": {"workload": "edge_computing env step, %d envs/GPU x %d agents, task_size_max=6000, "
+                                   "uniform-random policy over the avail mask, reset every %d steps "
+                                   "(BASELINE.json configs[1])" % (B, N, env.episode_limit),
+                       "envs_per_gpu": B, "agents": N, "launch": "eager" if a.no_graph else "hipGraph per episode",
+                       "geometry": env.info_geometry()},
+        }
+    if rank == 0 and world == 1:
+        avg_ms, med_ms, lbar, draws = measure_roofline(env, roll, a.roofline_steps)
+        bytes_step = algorithmic_bytes_per_env_step(N, lbar, draws) * B
+        achieved = bytes_step / (avg_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_step",
+                           "kernel_avg_us": avg_ms * 1e3, "kernel_median_us": med_ms * 1e3,
+                           "algorithmic_bytes_per_launch": bytes_step, "live_tasks_per_env": lbar,
+                           "rng_doubles_per_env_step": draws}
+        if a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(ns, env.tables, B, a.cpu_seconds)
+    env.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -110,9 +110,10 @@ int ec_step(ec_handle h, const int64_t* actions, float* reward, uint8_t* termina
 
 /* Uniform choice over the availability mask (stands in for action_selectors.py:6-8 with a
  * counter-based device RNG; NOT stream-compatible with torch's generator). avail [rows,A] i32,
- * actions [rows] i64. */
+ * actions [rows] i64.  counter_dev: NULL, or a zero-initialised device u64[2] whose first word is added
+ * to `counter` and incremented once per launch (lets a captured hipGraph draw fresh numbers per replay). */
 int ec_random_policy(const int32_t* avail, int64_t rows, int32_t n_actions, uint64_t seed, uint64_t counter,
-                     int64_t* actions, void* stream);
+                     uint64_t* counter_dev, int64_t* actions, void* stream);
 
 /* Device status word (EC_ST_* bits, sticky until cleared). Synchronises the stream. */
 int ec_status(ec_handle h, uint32_t* status_host, int clear, void* stream);
@@ -125,6 +126,8 @@ int ec_status(ec_handle h, uint32_t* status_host, int clear, void* stream);
 int ec_debug_dump(ec_handle h, int64_t env, double* rows_host, int64_t max_rows, int64_t* n_rows_host);
 /* words consumed so far from each MT19937 stream: cursors_host [B,N,2] (task, failure) u64 */
 int ec_debug_rng_cursors(ec_handle h, uint64_t* cursors_host);
+/* total live tasks over all envs (for the roofline's L-bar) */
+int ec_debug_live_tasks(ec_handle h, int64_t* total_host);
 /* geometry chosen by ec_create: {B, N, k, D(max in-degree), cap_buffer, cap_recv, cap_wait, max_ticks,
  * threads_per_block, envs_per_block, state_bytes_lo, state_bytes_hi} */
 int ec_info(ec_handle h, int64_t* info_host, int32_t n);

@@ -141,14 +141,15 @@ def lib():
     L.ec_reset.argtypes = [vp, vp]
     L.ec_observe.argtypes = [vp, vp, vp, vp]
     L.ec_step.argtypes = [vp] + [vp] * 8 + [vp]
-    L.ec_random_policy.argtypes = [vp, i64, i32, u64, u64, vp, vp]
+    L.ec_random_policy.argtypes = [vp, i64, i32, u64, u64, vp, vp, vp]
     L.ec_status.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, vp]
     L.ec_debug_dump.argtypes = [vp, i64, vp, i64, C.POINTER(i64)]
     L.ec_debug_rng_cursors.argtypes = [vp, vp]
     L.ec_info.argtypes = [vp, C.POINTER(i64), i32]
+    L.ec_debug_live_tasks.argtypes = [vp, C.POINTER(i64)]
     L.ec_gae.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, C.c_float, C.c_float, vp]
     for fn in ("ec_create", "ec_destroy", "ec_reset", "ec_observe", "ec_step", "ec_random_policy", "ec_status",
-               "ec_debug_dump", "ec_debug_rng_cursors", "ec_info", "ec_gae"):
+               "ec_debug_dump", "ec_debug_rng_cursors", "ec_debug_live_tasks", "ec_info", "ec_gae"):
         getattr(L, fn).restype = C.c_int
     L.ec_last_error.restype = C.c_char_p
     L.ec_version.restype = C.c_char_p

@@ -793,9 +793,23 @@ __global__ void k_copy_i32(const int32_t* __restrict__ src, int32_t* __restrict_
 }
 
 // Uniform choice over the availability mask with a counter-based generator (splitmix64 finaliser).
+// counter_dev (optional): word 0 = launch counter, word 1 = block ticket; the last block to finish bumps the
+// counter, so a captured hipGraph draws fresh numbers on every replay.
 __global__ void k_random_policy(const int32_t* __restrict__ avail, int64_t rows, int A, u64 seed, u64 counter,
-                                int64_t* __restrict__ actions) {
+                                u64* counter_dev, int64_t* __restrict__ actions) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (counter_dev) {
+        const u64 base = counter_dev[0];
+        counter += base;
+        __syncthreads();  // every thread of this block has read the counter
+        if (threadIdx.x == 0) {
+            const u64 t = atomicAdd((unsigned long long*)(counter_dev + 1), 1ull);
+            if (t == (u64)gridDim.x - 1) {  // all other blocks have read it too
+                counter_dev[1] = 0;
+                counter_dev[0] = base + 1;
+            }
+        }
+    }
     if (r >= rows) return;
     const int32_t* a = avail + r * A;
     int cnt = 0;
@@ -1159,11 +1173,11 @@ int ec_step(ec_handle h, const int64_t* actions, float* reward, uint8_t* termina
 }
 
 int ec_random_policy(const int32_t* avail, int64_t rows, int32_t n_actions, uint64_t seed, uint64_t counter,
-                     int64_t* actions, void* stream) {
+                     uint64_t* counter_dev, int64_t* actions, void* stream) {
     if (!avail || !actions || rows < 0 || n_actions < 1) return ec::fail(EC_EINVAL, "bad argument");
     if (rows == 0) return EC_OK;
     hipLaunchKernelGGL(k_random_policy, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, avail,
-                       rows, (int)n_actions, seed, counter, actions);
+                       rows, (int)n_actions, seed, counter, counter_dev, actions);
     EC_HIP(hipGetLastError());
     return EC_OK;
 }
@@ -1206,6 +1220,20 @@ int ec_debug_rng_cursors(ec_handle h, uint64_t* cursors_host) {
         cursors_host[2 * l + 0] = tmp[l];
         cursors_host[2 * l + 1] = tmp[P + l];
     }
+    return EC_OK;
+}
+
+int ec_debug_live_tasks(ec_handle h, int64_t* total_host) {
+    if (!h || !total_host) return ec::fail(EC_EINVAL, "null argument");
+    const size_t P = (size_t)h->d.P;
+    std::vector<u32> tmp(P * (size_t)(4 + h->d.D));
+    EC_HIP(hipDeviceSynchronize());
+    const u32* srcs[4] = {h->d.has_new, h->d.buf_len, h->d.wq_len, h->d.ex_n};
+    for (int i = 0; i < 4; i++) EC_HIP(hipMemcpy(tmp.data() + i * P, srcs[i], sizeof(u32) * P, hipMemcpyDeviceToHost));
+    EC_HIP(hipMemcpy(tmp.data() + 4 * P, h->d.rq_len, sizeof(u32) * P * h->d.D, hipMemcpyDeviceToHost));
+    int64_t t = 0;
+    for (u32 v : tmp) t += v;
+    *total_host = t;
     return EC_OK;
 }
 

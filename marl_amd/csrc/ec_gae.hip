@@ -56,10 +56,10 @@ __global__ void __launch_bounds__(64) k_gae(const float* __restrict__ r, const f
 
 extern "C" int ec_gae(const float* r, const float* v, const float* nv, const float* m, float* adv, int64_t B,
                       int64_t T, int64_t N, float gamma, float gamma_lambda, void* stream) {
-    if (!r || !v || !nv || !m || !adv) return ec::fail(EC_EINVAL, "ec_gae: null pointer");
     if (B < 0 || T < 0 || N < 0) return ec::fail(EC_EINVAL, "ec_gae: negative shape");
     const int64_t chains = B * N;
-    if (chains == 0 || T == 0) return EC_OK;
+    if (chains == 0 || T == 0) return EC_OK;  // empty batch: nothing to do (pointers may be null)
+    if (!r || !v || !nv || !m || !adv) return ec::fail(EC_EINVAL, "ec_gae: null pointer");
     hipLaunchKernelGGL(k_gae, dim3((unsigned)((chains + 63) / 64)), dim3(64), 0, (hipStream_t)stream, r, v, nv, m, adv,
                        B, T, N, gamma, gamma_lambda);
     EC_HIP(hipGetLastError());

@@ -125,13 +125,20 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
             info["hop_hist"] = self.hop_hist
         return self.reward, self.terminated, info
 
-    def random_actions(self, seed, counter, out=None):
-        """Uniform over the current availability mask (config 2 of BASELINE.json)."""
+    def random_actions(self, seed, counter, out=None, counter_dev=None):
+        """Uniform over the current availability mask (config 2 of BASELINE.json).  counter_dev: optional
+        zero-initialised int64[2] device tensor that advances once per launch (for hipGraph replays)."""
         avail = self.get_avail_actions()
         out = out if out is not None else th.empty(self.n_envs, self.n_agents, dtype=th.int64, device=self.device)
         _abi.check(self.lib.ec_random_policy(_ptr(avail), self.n_envs * self.n_agents, self.n_actions, int(seed),
-                                             int(counter), _ptr(out), self._stream()), "ec_random_policy")
+                                             int(counter), _ptr(counter_dev), _ptr(out), self._stream()),
+                   "ec_random_policy")
         return out
+
+    def live_tasks(self):
+        n = C.c_int64()
+        _abi.check(self.lib.ec_debug_live_tasks(self._h, C.byref(n)), "ec_debug_live_tasks")
+        return int(n.value)
 
     def status(self, clear=True):
         st = C.c_uint32(0)

@@ -590,3 +590,58 @@ int oc_gae(const float* r, const float* v, const float* nv, const float* m, floa
         }
     return 0;
 }
+
+/* ---------------------------------------------------------------- CPU baseline driver (bench.py cpu_baseline leg)
+ * Lock-step rollout with the same work per step as the GPU bench: observe (obs + avail) -> uniform choice
+ * over the mask (same counter-based hash as ec_random_policy) -> step; reset every episode_limit steps. */
+static int64_t pick_random(const int32_t* a, int A, uint64_t seed, uint64_t counter, uint64_t rows, uint64_t r) {
+    int cnt = 0;
+    for (int j = 0; j < A; j++) cnt += a[j] != 0;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter * rows + r + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    int pick = cnt > 0 ? (int)(((z >> 32) * (uint64_t)cnt) >> 32) : 0;
+    for (int j = 0; j < A; j++)
+        if (a[j] != 0) {
+            if (pick == 0) return j;
+            pick--;
+        }
+    return A - 1;
+}
+
+int oc_random_policy(const int32_t* avail, int64_t rows, int32_t A, uint64_t seed, uint64_t counter, int64_t* actions) {
+    for (int64_t r = 0; r < rows; r++) actions[r] = pick_random(avail + r * A, A, seed, counter, (uint64_t)rows, (uint64_t)r);
+    return 0;
+}
+
+int oc_rollout_random(oc_handle E, int64_t n_steps, uint64_t seed, double* reward_sum, int64_t* finished) {
+    int N = E->N, A = N + 1;
+    double* obs = (double*)malloc(sizeof(double) * E->B * N * 9);
+    int32_t* avail = (int32_t*)malloc(sizeof(int32_t) * E->B * N * A);
+    int64_t* act = (int64_t*)malloc(sizeof(int64_t) * E->B * N);
+    double* rew = (double*)malloc(sizeof(double) * E->B);
+    int32_t* cnt = (int32_t*)malloc(sizeof(int32_t) * E->B * 4);
+    double rs = 0;
+    int64_t fin = 0;
+    for (int64_t t = 0; t < n_steps; t++) {
+        if (t % E->cfg.episode_limit == 0) oc_reset(E);
+        oc_observe(E, obs, avail);
+#pragma omp parallel for num_threads(E->n_threads) schedule(static)
+        for (int64_t r = 0; r < E->B * N; r++)
+            act[r] = pick_random(avail + r * A, A, seed, (uint64_t)t, (uint64_t)(E->B * N), (uint64_t)r);
+        oc_step(E, act, rew, NULL, cnt, NULL, NULL);
+        for (int64_t e = 0; e < E->B; e++) {
+            rs += rew[e];
+            fin += cnt[4 * e];
+        }
+    }
+    free(obs);
+    free(avail);
+    free(act);
+    free(rew);
+    free(cnt);
+    if (reward_sum) *reward_sum = rs;
+    if (finished) *finished = fin;
+    return 0;
+}

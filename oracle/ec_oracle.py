@@ -43,6 +43,8 @@ def lib():
         L.oc_rng_task_draws.argtypes = [C.c_uint32, C.c_double, i64] + [C.c_double] * 4 + [vp]
         L.oc_rng_task_draws.restype = None
         L.oc_gae.argtypes = [vp] * 5 + [i64] * 3 + [C.c_float, C.c_float]
+        L.oc_random_policy.argtypes = [vp, i64, C.c_int32, C.c_uint64, C.c_uint64, vp]
+        L.oc_rollout_random.argtypes = [vp, i64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(i64)]
         _lib = L
     return _lib
 
@@ -61,6 +63,14 @@ def rng_task_draws(seed, p, n, smin, smax, cmin, cmax):
     out = np.empty((n, 4), dtype=np.float64)
     lib().oc_rng_task_draws(int(seed) & 0xFFFFFFFF, p, n, smin, smax, cmin, cmax, _p(out))
     return out
+
+
+def random_policy(avail, seed, counter):
+    a = np.ascontiguousarray(avail, dtype=np.int32)
+    rows, A = a.reshape(-1, a.shape[-1]).shape
+    out = np.empty(rows, dtype=np.int64)
+    lib().oc_random_policy(_p(a), rows, A, int(seed), int(counter), _p(out))
+    return out.reshape(a.shape[:-1])
 
 
 def gae(r, v, nv, m, gamma, lam):
@@ -129,6 +139,12 @@ class OracleEnv:
         cur = np.empty((self.B, self.N, 2), dtype=np.uint64)
         lib().oc_debug_rng_cursors(self._h, _p(cur))
         return cur
+
+    def rollout_random(self, n_steps, seed=0):
+        """bench.py cpu_baseline leg: observe -> random-valid policy -> step, lock-step, reset per episode"""
+        rs, fin = C.c_double(), C.c_int64()
+        lib().oc_rollout_random(self._h, int(n_steps), int(seed), C.byref(rs), C.byref(fin))
+        return rs.value, fin.value
 
     def live_tasks(self):
         return int(lib().oc_live_tasks(self._h))

@@ -164,14 +164,15 @@ def test_bad_action_sets_status():
     env.reset()
     N = args.edge_node_num
     idle = th.full((4, N), N, dtype=th.int64, device=env.device)
-    for _ in range(3):
+    for _ in range(5):
         env.step(idle)
     assert env.status() == 0
-    # node 0 is adjacent to 1 and 9 only: 5 is the reference's ZeroDivisionError path
+    # node 7 (task probability 0.92) is adjacent to 2, 6 and 8 only: 0 is the reference's
+    # ZeroDivisionError path (transmission_rates[0] == 0, edge_node.py:227)
     bad = idle.clone()
-    has_task = env.get_avail_actions()[:, 0, N] == 0
+    has_task = env.get_avail_actions()[:, 7, N] == 0
     assert bool(has_task.any())
-    bad[:, 0] = 5
+    bad[:, 7] = 0
     env.step(bad)
     assert env.status(clear=False) & _abi.EC_ST_BAD_ACTION
     with pytest.raises(ZeroDivisionError):
