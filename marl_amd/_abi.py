@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmarl_amd.so")
+LIB_PATH = os.environ.get("MARL_AMD_LIB") or os.path.join(_HERE, "csrc", "libmarl_amd.so")
 
 EC_OK = 0
 EC_ST_BAD_ACTION = 1

@@ -10,13 +10,19 @@
 // Formulation: one lane per (env, node).  The reference walks every queue every
 // mini-slot and adds 0.05 to Python floats; here every timer is an integer tick count, a timer's fp64
 // value is acc[n] (acc[n] = acc[n-1] + mini_time_slot, the same rounding sequence the reference
-// produces), and waiting is accounted lazily from enqueue ticks, so a mini-slot touches memory only
-// when something happens to a task.  Deadline / completion thresholds are turned into integer tick
+// produces), and waiting is accounted lazily from enqueue ticks, so a mini-slot touches a task only
+// when something happens to it.  Deadline / completion thresholds are turned into integer tick
 // thresholds once per task by evaluating the reference's left-to-right fp64 sum on the LUT.
 //
-// Layout: every per-node array is [slot][P] with P = B*N lanes minor, so that a wave's access to
-// "slot s of my queue" is one contiguous run; task records are 32-byte (two dwordx4) elements.
-// MT19937 state is per lane [P][624] and advanced incrementally (one word regenerated per word drawn).
+// Memory plan of k_step: the working set of a lane (its executing slots, its waiting queue, the head
+// of each receiving queue, the next doubles of both MT19937 streams, the low part of the tick LUT) is
+// staged into LDS/registers with independent, lane-contiguous loads at kernel entry, the ten
+// mini-slots then run out of LDS, and the set is written back at exit; global memory is touched
+// inside the mini-slot loop only for the rare deep-queue cases.
+//
+// Layout: every per-node array is [slot][P] with P = B*N lanes minor, so a wave's access to "slot s of
+// my queue" is one contiguous run; task records are 32-byte (two dwordx4) elements.  MT19937 state is
+// per lane [P][624], regenerated in place ahead of consumption in 32-word batches.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -34,6 +40,9 @@ constexpr int MT_N = 624;
 constexpr int MT_M = 397;
 constexpr u32 NEVER = 0xFFFFFFFFu;
 constexpr u32 T16_NEVER = 0xFFFFu;
+constexpr int RB_FAIL = 48;  // draws of the failure stream held in the LDS window (>= KMAX + DMAX)
+constexpr int RB_TASK = 4;   // doubles of the task stream staged per refill (binomial + id + size + cycles)
+constexpr int ACC_LDS = 256; // low part of the tick LUT kept in LDS
 
 // task record while in buffer_queue / new_task / a receiving queue (32 B)
 struct __attribute__((aligned(16))) Rec {
@@ -46,34 +55,58 @@ struct __attribute__((aligned(16))) Rec {
     int32_t bwt;    // buffer_waiting_time ticks; inside buffer_queue: bias = bwt - n_off at entry
     u32 enq;        // receiving queue: index of the first receive_task call after the push
 };
+static_assert(sizeof(Rec) == 32, "record size");
 
-// task record while in execution_queue (waiting, 32 B)
-struct __attribute__((aligned(16))) WRec {
-    double et;    // execute_time = cycles / cpu_capacity (edge_node.py:220)
-    u32 enq;      // index of the first execute_task call after the push
-    u32 drop_at;  // execute_task call index at which the deadline sweep drops it (edge_node.py:299-309)
-    u16 nexec;    // min n with acc[n] >= et
-    u16 twt, ctt, bwt;
-    u16 hop;
-    u16 pad[3];
+// waiting-queue (execution_queue) entry: 16-byte meta + fp64 execute_time
+//   meta.x = enq   index of the first execute_task call after the push
+//   meta.y = nd | nexec << 16     nd: the deadline sweep drops it at call enq + nd - 1 (edge_node.py:299-309)
+//                                 nexec: min n with acc[n] >= execute_time
+//   meta.z = twt | ctt << 16
+//   meta.w = bwt | hop << 16
+struct WMeta {
+    u32 enq, nd, nexec, twt, ctt, bwt, hop;
 };
+__device__ __forceinline__ uint4 wmeta_pack(const WMeta& m) {
+    return make_uint4(m.enq, (m.nd & 0xffffu) | (m.nexec << 16), (m.twt & 0xffffu) | (m.ctt << 16),
+                      (m.bwt & 0xffffu) | (m.hop << 16));
+}
+__device__ __forceinline__ WMeta wmeta_unpack(const uint4 v) {
+    WMeta m;
+    m.enq = v.x;
+    m.nd = v.y & 0xffffu;
+    m.nexec = v.y >> 16;
+    m.twt = v.z & 0xffffu;
+    m.ctt = v.z >> 16;
+    m.bwt = v.w & 0xffffu;
+    m.hop = v.w >> 16;
+    return m;
+}
+__device__ __forceinline__ u32 wmeta_drop_at(const uint4 v) {
+    const u32 nd = v.y & 0xffffu;
+    return nd == T16_NEVER ? NEVER : v.x + nd - 1;
+}
 
-static_assert(sizeof(Rec) == 32 && sizeof(WRec) == 32, "record size");
+struct FastDiv {
+    u32 d, m;
+};
 
 struct EcDev {
     // geometry
     int N, A, k, D, S, T, H;
     int capB, capR, capW, maxTicks;
+    int epb;       // environments per block (launch geometry)
+    int dl_ticks;  // (int)(deadline / mini_time_slot): starting point of the deadline searches
+    FastDiv divN, divA;
     int64_t B, P;
     // scalars
-    double dt, deadline;
+    double dt, inv_dt, deadline;
     double size_lo, size_range, cx_lo, cx_range;
     double pen_drop, pen_fail, rew_succ, pen_hop;
     double obs_size_norm, obs_cyc_norm;
     // constant tables
     const double* acc;        // [maxTicks+1]
     const double* cap;        // [N]
-    const double* thr_exec;   // [N] exp(-efr*dt)
+    const u64* thr_exec_m;    // [N] floor(exp(-efr*dt) * 2^53)
     const double* qlen;       // [N]
     const double* qthr;       // [N] qlen * rl_queue_coeff
     const float* obs_const;   // [N][3]
@@ -82,37 +115,39 @@ struct EcDev {
     const uint8_t* bin_flip;  // [N] p > 0.5
     const int* deg;           // [N] in-degree
     const int* in_src;        // [N][D] ascending source ids
-    const double* thr_link;   // [N][D] exp(-tfr[src][dst]*dt)
+    const u64* thr_link_m;    // [N][D] floor(exp(-tfr[src][dst]*dt) * 2^53)
     const int* slot_of;       // [N(src)][N(dst)] slot of src in dst's in-list, -1 if not adjacent
     const double* rate;       // [N][N]
     const uint8_t* adj;       // [N][A]
+    const u64* adj_bits;      // [N] adj rows as bit masks (N <= 64), else null
     // per-lane state
-    u32* mt;       // [2][P][624]
-    u32* rng_pos;  // [2][P]
-    u64* rng_cnt;  // [2][P]
-    u32* has_new;  // [P]
-    Rec* newt;     // [P]
-    u32* buf_head; // [P]
-    u32* buf_len;  // [P]
-    Rec* buf;      // [capB][P]
-    u32* wq_head;  // [P]
-    u32* wq_len;   // [P]
-    u32* wq_min;   // [P] lower bound of min drop_at over the waiting queue
-    WRec* wq;      // [capW][P]
-    u32* ex_n;     // [P]
-    u64* exA;      // [k][P] {cet, drop_cet, nexec, hop}
-    u64* exB;      // [k][P] {ewt, twt, ctt, bwt}
-    u32* rq_head;  // [D][P]
-    u32* rq_len;   // [D][P]
-    u32* rq_arrive;// [D][P] receive_task call index at which the head arrives
-    u32* rq_hstart;// [D][P] first call index with the current head as head
-    Rec* rq;       // [D][capR][P]
-    u32* n_off;    // [P] offload events (lazy buffer_waiting_time)
+    u32* mt;        // [2][P][624]
+    u32* rng_pos;   // [2][P] next word to consume
+    u32* rng_ahead; // [2][P] words already regenerated beyond rng_pos
+    u64* rng_cnt;   // [2][P] words consumed so far
+    u32* has_new;   // [P]
+    Rec* newt;      // [P]
+    u32* buf_head;  // [P]
+    u32* buf_len;   // [P]
+    Rec* buf;       // [capB][P] ring
+    u32* wq_len;    // [P]
+    uint4* wqm;     // [capW][P] linear (index 0 = head)
+    double* wqe;    // [capW][P]
+    u32* ex_n;      // [P]
+    u64* exA;       // [k][P] cet | fin << 16 | hop << 32 | success << 48
+    double* exB;    // [k][P] task_time at cet == fin
+    u64* exC;       // [k][P] {ewt, twt, ctt, bwt}
+    u32* rq_head;   // [D][P]
+    u32* rq_len;    // [D][P]
+    u32* rq_arrive; // [D][P] receive_task call index at which the head arrives
+    u32* rq_hstart; // [D][P] first call index with the current head as head
+    Rec* rq;        // [D][capR][P] rings
+    u32* n_off;     // [P] offload events (lazy buffer_waiting_time)
     // per-env state
-    u32* cur_step; // [B]
-    u32* tick;     // [B] execute/receive call index
+    u32* cur_step;  // [B]
+    u32* tick;      // [B] execute/receive call index
     int32_t* hop_hist;  // [B][H]
-    u32* status;   // [1]
+    u32* status;    // [1]
 };
 
 // ------------------------------------------------------------------------------------------ helpers
@@ -122,13 +157,50 @@ __device__ __forceinline__ double ddiv(double a, double b) { return __ddiv_rn(a,
 
 __device__ __forceinline__ void flag(const EcDev& d, u32 bit) { atomicOr(d.status, bit); }
 
-__device__ __forceinline__ double lut(const EcDev& d, u32 n) {
-    if (n > (u32)d.maxTicks) {
-        flag(d, EC_ST_TICK_OVERFLOW);
-        n = d.maxTicks;
+// tick LUT: low entries from LDS (when s_acc != nullptr), the rest from global.  An index beyond the LUT is
+// clamped and remembered in `ovf` (reported through the status word by the caller).
+struct Lut {
+    const EcDev& d;
+    const double* s_acc;
+    mutable u32 ovf;
+    __device__ __forceinline__ double at(u32 n) const {
+        ovf |= n > (u32)d.maxTicks ? 1u : 0u;
+        n = n > (u32)d.maxTicks ? (u32)d.maxTicks : n;
+        if (s_acc && n < (u32)ACC_LDS) return s_acc[n];
+        return d.acc[n];
     }
-    return d.acc[n];
-}
+    // smallest n with acc[n] >= x, T16_NEVER if none in the LUT
+    __device__ __forceinline__ u32 ticks_to_reach(double x) const {
+        const double est = x * d.inv_dt;  // only a starting point: the search below is exact
+        u32 n = 0;
+        if (est > 3.0) n = est >= (double)d.maxTicks ? (u32)d.maxTicks : (u32)est - 3u;
+        while (n <= (u32)d.maxTicks && at(n) < x) n++;
+        return n > (u32)d.maxTicks ? T16_NEVER : n;
+    }
+    // The reference's task_time (edge_node.py:255,301): ((((ewt + cet) + twt) + ctt) + bwt) in fp64.
+    __device__ __forceinline__ double task_time(u32 ewt, u32 cet, u32 twt, u32 ctt, u32 bwt) const {
+        return dadd(dadd(dadd(dadd(at(ewt), at(cet)), at(twt)), at(ctt)), at(bwt));
+    }
+    // smallest n >= 1 such that task_time with the free timer at n ticks exceeds the deadline, and that
+    // task_time.  which = 0: free timer is ewt (cet = 0);  which = 1: free timer is cet (ewt fixed).
+    __device__ __forceinline__ u32 deadline_ticks(int which, u32 ewt, u32 twt, u32 ctt, u32 bwt, double* tt_out) const {
+        const u32 others = twt + ctt + bwt + (which ? ewt : 0u);
+        const int nominal = d.dl_ticks - (int)others - 1;
+        u32 n = nominal < 1 ? 1u : (u32)nominal;
+        const double tail0 = at(twt), tail1 = at(ctt), tail2 = at(bwt), fixed = which ? at(ewt) : 0.0;
+        while (n <= (u32)d.maxTicks) {
+            const double head = which ? dadd(fixed, at(n)) : dadd(at(n), 0.0);
+            const double tt = dadd(dadd(dadd(head, tail0), tail1), tail2);
+            if (tt > d.deadline) {
+                *tt_out = tt;
+                return n;
+            }
+            n++;
+        }
+        *tt_out = 0.0;
+        return T16_NEVER;
+    }
+};
 
 template <typename R>
 __device__ __forceinline__ R load_rec(const R* p) {
@@ -153,14 +225,6 @@ __device__ __forceinline__ void store_rec(R* p, const R& r) {
     q[1] = u.v[1];
 }
 
-// Incremental MT19937: position p is regenerated at the moment it is consumed, which yields the same
-// word sequence as the block twist of numpy's mt19937_gen (positions are regenerated in the same order
-// from the same neighbours).  Only 53-bit doubles are drawn, so pos stays even.
-struct Rng {
-    u32* mt;
-    u32 pos;
-    u32 used;
-};
 __device__ __forceinline__ u32 mt_temper(u32 y) {
     y ^= (y >> 11);
     y ^= (y << 7) & 0x9d2c5680u;
@@ -169,94 +233,219 @@ __device__ __forceinline__ u32 mt_temper(u32 y) {
     return y;
 }
 __device__ __forceinline__ u32 mt_next(u32 cur, u32 nxt, u32 far) {
-    u32 y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+    const u32 y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
     return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
-__device__ __forceinline__ double rng_double(Rng& r) {
-    const u32 p = r.pos;  // even, <= 622
-    u32 p2 = p + 2;
-    if (p2 == MT_N) p2 = 0;
-    u32 q0 = p + MT_M;
-    if (q0 >= MT_N) q0 -= MT_N;
-    u32 q1 = q0 + 1;
-    if (q1 == MT_N) q1 = 0;
-    const uint2 a01 = *reinterpret_cast<const uint2*>(r.mt + p);
-    const u32 a2 = r.mt[p2];
-    const u32 b0 = r.mt[q0];
-    const u32 b1 = r.mt[q1];
-    const u32 n0 = mt_next(a01.x, a01.y, b0);
-    const u32 n1 = mt_next(a01.y, a2, b1);
-    *reinterpret_cast<uint2*>(r.mt + p) = make_uint2(n0, n1);
-    r.pos = p2;
-    r.used += 2;
-    const u32 a = mt_temper(n0) >> 5, b = mt_temper(n1) >> 6;
-    // (a * 2^26 + b) / 2^53, exact in fp64 (numpy random_sample)
-    return (double)(((u64)a << 26) | (u64)b) * (1.0 / 9007199254740992.0);
+__device__ __forceinline__ u32 mt_wrap(u32 p) { return p >= (u32)MT_N ? p - MT_N : p; }
+// numpy random_sample: (a * 2^26 + b) / 2^53 with a = w0 >> 5, b = w1 >> 6 — every step exact in fp64
+__device__ __forceinline__ double mt_to_double(u32 w0, u32 w1) {
+    const u32 a = mt_temper(w0) >> 5, b = mt_temper(w1) >> 6;
+    return __fma_rn((double)a, 1.0 / 134217728.0, (double)b * (1.0 / 9007199254740992.0));
 }
 
-// smallest n >= lo with acc[n] >= x, T16_NEVER if none in the LUT
-__device__ __forceinline__ u32 ticks_to_reach(const EcDev& d, double x) {
-    double est = x / d.dt;
-    u32 n = 0;
-    if (est > 2.0) n = est >= (double)d.maxTicks ? (u32)d.maxTicks : (u32)est - 2u;
-    while (n <= (u32)d.maxTicks && d.acc[n] < x) n++;
-    return n > (u32)d.maxTicks ? T16_NEVER : n;
-}
-
-// The reference's task_time (edge_node.py:255,301): ((((ewt + cet) + twt) + ctt) + bwt) in fp64.
-__device__ __forceinline__ double task_time(const EcDev& d, u32 ewt, u32 cet, u32 twt, u32 ctt, u32 bwt) {
-    return dadd(dadd(dadd(dadd(lut(d, ewt), lut(d, cet)), lut(d, twt)), lut(d, ctt)), lut(d, bwt));
-}
-
-// smallest n >= 1 such that task_time with the free timer at n ticks exceeds the deadline.
-// which = 0: free timer is ewt (cet = 0);  which = 1: free timer is cet (ewt fixed).
-__device__ __forceinline__ u32 deadline_ticks(const EcDev& d, int which, u32 ewt, u32 twt, u32 ctt, u32 bwt) {
-    const u32 others = twt + ctt + bwt + (which ? ewt : 0u);
-    const long nominal = (long)(d.deadline / d.dt) - (long)others - 1;
-    u32 n = nominal < 1 ? 1u : (u32)nominal;
-    while (n <= (u32)d.maxTicks) {
-        const double tt = which ? task_time(d, ewt, n, twt, ctt, bwt) : task_time(d, n, 0, twt, ctt, bwt);
-        if (tt > d.deadline) return n;
-        n++;
+// MT19937 stream of one lane (numpy RandomState / mt19937_gen).  Positions are regenerated in place and in
+// order, possibly `ahead` words beyond the consumption cursor `pos`: a word at position q needs the
+// not-yet-regenerated word q+1 and the current word (q+397) mod 624, which in-order regeneration provides
+// for any batch shorter than 227 words.  Only 53-bit doubles (two words) are drawn, so pos stays even.
+//
+// One pair: returns the (regenerated) words at positions q, q+1.  `fresh`: the pair was regenerated by an
+// earlier batch and only needs to be read.
+struct MtPairIn {
+    uint2 cur;
+    u32 nxt, f0, f1;
+};
+__device__ __forceinline__ MtPairIn mt_pair_load(const u32* mt, u32 q, bool fresh) {
+    MtPairIn in;
+    in.cur = *reinterpret_cast<const uint2*>(mt + q);
+    in.nxt = in.f0 = in.f1 = 0;
+    if (!fresh) {
+        in.nxt = mt[mt_wrap(q + 2)];
+        in.f0 = mt[mt_wrap(q + MT_M)];
+        in.f1 = mt[mt_wrap(q + MT_M + 1)];
     }
-    return T16_NEVER;
+    return in;
 }
+__device__ __forceinline__ uint2 mt_pair_finish(u32* mt, u32 q, bool fresh, const MtPairIn& in) {
+    if (fresh) return in.cur;
+    const uint2 n = make_uint2(mt_next(in.cur.x, in.cur.y, in.f0), mt_next(in.cur.y, in.nxt, in.f1));
+    *reinterpret_cast<uint2*>(mt + q) = n;
+    return n;
+}
+
+// Failure stream (edge_node.py:258,322): the tests are `random() > threshold` with random() =
+// (a*2^26 + b) / 2^53, i.e. the integer test  a*2^26 + b > M  with M = floor(threshold * 2^53)  (exact: see
+// DESIGN.md).  With A = M >> 26 that is  a > A || (a == A && b > (M & (2^26-1))), so the window keeps only the
+// 27-bit `a` of each draw (LDS, [draw][stride]); the second word is read back from the regenerated state in
+// the 2^-27 tie case.
+struct RngFail {
+    u32* mt;
+    u32 pos, ahead;  // cursor of the window start; words regenerated beyond it
+    u32 idx;         // draws consumed from the window
+    u32 staged;      // draws in the window
+    u32 used;        // draws consumed in windows already retired
+    u32* buf;
+    int stride;
+
+    // stage draws [0, n) of the window (n <= capacity); regenerates whatever is not yet regenerated
+    __device__ __forceinline__ void stage(u32 n) {
+        for (u32 i0 = 0; i0 < n; i0 += 4) {
+            MtPairIn in[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 i = i0 + j;
+                if (i < n) in[j] = mt_pair_load(mt, mt_wrap(pos + 2 * i), 2 * i < ahead);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 i = i0 + j;
+                if (i < n) {
+                    const uint2 w = mt_pair_finish(mt, mt_wrap(pos + 2 * i), 2 * i < ahead, in[j]);
+                    buf[i * stride] = mt_temper(w.x) >> 5;
+                }
+            }
+        }
+        ahead = ahead > 2 * n ? ahead : 2 * n;
+        staged = n;
+        idx = 0;
+    }
+    __device__ __forceinline__ void open(u32* mt_, u32 pos_, u32 ahead_, u32* buf_, int stride_, u32 n) {
+        mt = mt_;
+        pos = pos_;
+        ahead = ahead_;
+        buf = buf_;
+        stride = stride_;
+        used = 0;
+        stage(n);
+    }
+    // slide the window so that it starts at the next unconsumed draw (rare: only when a lane's per-step bound
+    // exceeds the window capacity)
+    __device__ __noinline__ void restage(u32 n) {
+        pos = mt_wrap(pos + 2 * idx);
+        ahead -= 2 * idx;
+        used += idx;
+        stage(n);
+    }
+    // second word of window draw i, as numpy's b = word >> 6
+    __device__ __forceinline__ u32 b_of(u32 i) const { return mt_temper(mt[mt_wrap(pos + 2 * i + 1)]) >> 6; }
+    __device__ __forceinline__ void close(u32& pos_out, u32& ahead_out, u32& draws) const {
+        pos_out = mt_wrap(pos + 2 * idx);
+        ahead_out = ahead - 2 * idx;
+        draws = used + idx;
+    }
+};
+
+// Task stream (edge_node.py:161, task.py:10-12): at most 4 doubles per step (binomial, id, size, cycles) except
+// for the 2^-53 binomial redraw; the four are produced up front into registers.
+struct RngTask {
+    u32* mt;
+    u32 pos, ahead;
+    u32 idx, used;
+    double u[RB_TASK];
+    __device__ __forceinline__ void stage() {
+        MtPairIn in[RB_TASK];
+#pragma unroll
+        for (int i = 0; i < RB_TASK; i++) in[i] = mt_pair_load(mt, mt_wrap(pos + 2 * i), 2u * i < ahead);
+#pragma unroll
+        for (int i = 0; i < RB_TASK; i++) {
+            const uint2 w = mt_pair_finish(mt, mt_wrap(pos + 2 * i), 2u * i < ahead, in[i]);
+            u[i] = mt_to_double(w.x, w.y);
+        }
+        ahead = ahead > 2u * RB_TASK ? ahead : 2u * RB_TASK;
+        idx = 0;
+    }
+    __device__ __forceinline__ void open(u32* mt_, u32 pos_, u32 ahead_) {
+        mt = mt_;
+        pos = pos_;
+        ahead = ahead_;
+        used = 0;
+        stage();
+    }
+    __device__ __forceinline__ double next() {
+        if (idx == (u32)RB_TASK) {  // only after a binomial redraw
+            pos = mt_wrap(pos + 2 * idx);
+            ahead -= 2 * idx;
+            used += idx;
+            stage();
+        }
+        double r = u[0];
+#pragma unroll
+        for (int i = 1; i < RB_TASK; i++) r = idx == (u32)i ? u[i] : r;
+        idx++;
+        return r;
+    }
+    __device__ __forceinline__ void close(u32& pos_out, u32& ahead_out, u32& draws) const {
+        pos_out = mt_wrap(pos + 2 * idx);
+        ahead_out = ahead - 2 * idx;
+        draws = used + idx;
+    }
+};
+
+// Draw-at-consumption form of the same generator (ahead must be 0): used by the constructor pass only.
+struct RngDirect {
+    u32* mt;
+    u32 pos;
+    u32 used;
+    __device__ __forceinline__ double next() {
+        const MtPairIn in = mt_pair_load(mt, pos, false);
+        const uint2 n = mt_pair_finish(mt, pos, false, in);
+        pos = mt_wrap(pos + 2);
+        used += 1;
+        return mt_to_double(n.x, n.y);
+    }
+};
 
 __device__ __forceinline__ u64 pack4(u32 a, u32 b, u32 c, u32 e) {
     return (u64)(a & 0xffffu) | ((u64)(b & 0xffffu) << 16) | ((u64)(c & 0xffffu) << 32) | ((u64)(e & 0xffffu) << 48);
 }
 __device__ __forceinline__ u32 f16(u64 w, int i) { return (u32)((w >> (16 * i)) & 0xffffu); }
 
-__device__ __forceinline__ u32 clamp16(const EcDev& d, u32 v) {
-    if (v > 0xfffeu) {
-        flag(d, EC_ST_TICK_OVERFLOW);
-        v = 0xfffeu;
-    }
-    return v;
+__device__ __forceinline__ u32 sat16(u32 v, u32& ovf) {
+    ovf |= v > 0xfffeu ? 1u : 0u;
+    return v > 0xfffeu ? 0xfffeu : v;
 }
 
-// append to this lane's buffer_queue (edge_node.py:163,333); rec.bwt holds the true tick count
-__device__ __forceinline__ void buffer_push(const EcDev& d, int64_t lane, u32& head, u32& len, u32 n_off, Rec rec) {
-    if (len >= (u32)d.capB) {
-        flag(d, EC_ST_BUFFER_OVERFLOW);
-        return;
+// n / dv.d for n below 2^32 / dv.d (m = ceil(2^32 / d)); d == 1 is the identity
+__device__ __forceinline__ u32 fdiv(u32 n, FastDiv dv) { return dv.d == 1 ? n : __umulhi(n, dv.m); }
+
+// buffer_queue of one lane.  generate_task pops whenever the queue is non-empty (edge_node.py:165-166), i.e. the
+// head is consumed at the end of EVERY step: `head_rec` is that record, prefetched at kernel entry or captured
+// when a push finds the queue empty (such a record never needs to reach the global ring).
+struct Buffer {
+    u32 head, len;
+    Rec head_rec;
+    __device__ __forceinline__ void push(const EcDev& d, int64_t lane, u32 n_off, Rec rec) {
+        if (len >= (u32)d.capB) {
+            flag(d, EC_ST_BUFFER_OVERFLOW);
+            return;
+        }
+        rec.bwt = rec.bwt - (int32_t)n_off;  // edge_node.py:214-216 applied lazily
+        if (len == 0) {
+            head_rec = rec;
+        } else {
+            u32 pos = head + len;
+            if (pos >= (u32)d.capB) pos -= d.capB;
+            store_rec(d.buf + (size_t)pos * d.P + lane, rec);
+        }
+        len++;
     }
-    rec.bwt = rec.bwt - (int32_t)n_off;
-    u32 pos = head + len;
-    if (pos >= (u32)d.capB) pos -= d.capB;
-    store_rec(d.buf + (size_t)pos * d.P + lane, rec);
-    len++;
-}
+    __device__ __forceinline__ Rec pop(const EcDev& d, u32 n_off) {
+        Rec r = head_rec;
+        r.bwt = r.bwt + (int32_t)n_off;
+        head = head + 1 == (u32)d.capB ? 0u : head + 1;
+        len--;
+        return r;
+    }
+};
 
 // edge_node.py:159-166 + task.py:6-33
-__device__ __forceinline__ void generate_task(const EcDev& d, int64_t lane, int node, Rng& trng, u32& buf_head,
-                                              u32& buf_len, u32 n_off, u32& has_new, Rec& newt) {
+template <typename RNG>
+__device__ __forceinline__ void generate_task(const EcDev& d, int64_t lane, double qn, double px2, u32 flip,
+                                              RNG& trng, Buffer& buf, u32 n_off, u32& has_new, Rec& newt) {
     has_new = 0;
     // numpy legacy binomial(1, p): inversion with bound = 1 (see oracle/ec_oracle.c binomial_inversion)
-    const double qn = d.bin_qn[node], px2 = d.bin_px2[node];
     u32 X;
     for (;;) {
-        double U = rng_double(trng);
+        double U = trng.next();
         if (!(U > qn)) {
             X = 0;
             break;
@@ -268,30 +457,19 @@ __device__ __forceinline__ void generate_task(const EcDev& d, int64_t lane, int 
         }
         // X would exceed the bound: redraw (probability ~2^-53)
     }
-    const u32 arrival = d.bin_flip[node] ? 1u - X : X;
-    bool direct = false;
+    const u32 arrival = flip ? 1u - X : X;
     if (arrival) {
-        (void)rng_double(trng);  // task.id
+        (void)trng.next();  // task.id
         Rec t;
-        t.size = dmul(dmul(dadd(d.size_lo, dmul(d.size_range, rng_double(trng))), 1024.0), 8.0);
-        t.cycles = dmul(dadd(d.cx_lo, dmul(d.cx_range, rng_double(trng))), t.size);
+        t.size = dmul(dmul(dadd(d.size_lo, dmul(d.size_range, trng.next())), 1024.0), 8.0);
+        t.cycles = dmul(dadd(d.cx_lo, dmul(d.cx_range, trng.next())), t.size);
         t.twt = t.ctt = t.hop = t.ntx = 0;
         t.bwt = 0;
         t.enq = 0;
-        if (buf_len == 0) {
-            newt = t;  // push then pop of an empty queue
-            direct = true;
-        } else {
-            buffer_push(d, lane, buf_head, buf_len, n_off, t);
-        }
+        buf.push(d, lane, n_off, t);
     }
-    if (direct) {
-        has_new = 1;
-    } else if (buf_len > 0) {
-        newt = load_rec(d.buf + (size_t)buf_head * d.P + lane);
-        newt.bwt = newt.bwt + (int32_t)n_off;
-        buf_head = buf_head + 1 == (u32)d.capB ? 0u : buf_head + 1;
-        buf_len--;
+    if (buf.len > 0) {
+        newt = buf.pop(d, n_off);
         has_new = 1;
     }
 }
@@ -303,13 +481,17 @@ struct LaneId {
 };
 __device__ __forceinline__ LaneId lane_id(const EcDev& d) {
     LaneId L;
-    const int epb = blockDim.x / d.N;
-    L.env_local = threadIdx.x / d.N;
+    L.env_local = (int)fdiv(threadIdx.x, d.divN);
     L.node = threadIdx.x - L.env_local * d.N;
-    L.env = (int64_t)blockIdx.x * epb + L.env_local;
-    L.valid = L.env_local < epb && L.env < d.B;
+    L.env = (int64_t)blockIdx.x * d.epb + L.env_local;
+    L.valid = L.env_local < d.epb && L.env < d.B;
     L.lane = L.env * d.N + L.node;
     return L;
+}
+
+__device__ __forceinline__ u32 arrive_at(u32 hstart, u32 ntx, u32 ctt) {
+    if (ntx == T16_NEVER) return NEVER;
+    return hstart + (ntx > ctt + 1 ? ntx - ctt - 1 : 0u);
 }
 
 // ------------------------------------------------------------------------------------------ kernels
@@ -326,12 +508,12 @@ __global__ void k_seed(EcDev d, u32 task_seed0, u32 fail_seed0) {
             seed = 1812433253u * (seed ^ (seed >> 30)) + (u32)(i + 1);
         }
         d.rng_pos[(size_t)s * d.P + lane] = 0;
+        d.rng_ahead[(size_t)s * d.P + lane] = 0;
         d.rng_cnt[(size_t)s * d.P + lane] = 0;
     }
     d.has_new[lane] = 0;
     d.buf_head[lane] = d.buf_len[lane] = 0;
-    d.wq_head[lane] = d.wq_len[lane] = 0;
-    d.wq_min[lane] = NEVER;
+    d.wq_len[lane] = 0;
     d.ex_n[lane] = 0;
     d.n_off[lane] = 0;
     for (int s = 0; s < d.D; s++) {
@@ -352,14 +534,17 @@ __global__ void k_initial_generate(EcDev d) {
     const int64_t lane = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= d.P) return;
     const int node = (int)(lane % d.N);
-    Rng trng{d.mt + (size_t)lane * MT_N, d.rng_pos[lane], 0};
-    u32 bh = d.buf_head[lane], bl = d.buf_len[lane], hn;
+    RngDirect trng{d.mt + (size_t)lane * MT_N, d.rng_pos[lane], 0};
+    Buffer buf;
+    buf.head = d.buf_head[lane];
+    buf.len = d.buf_len[lane];  // 0 at construction
+    u32 hn;
     Rec nt;
-    generate_task(d, lane, node, trng, bh, bl, d.n_off[lane], hn, nt);
+    generate_task(d, lane, d.bin_qn[node], d.bin_px2[node], d.bin_flip[node], trng, buf, d.n_off[lane], hn, nt);
     d.rng_pos[lane] = trng.pos;
-    d.rng_cnt[lane] += trng.used;
-    d.buf_head[lane] = bh;
-    d.buf_len[lane] = bl;
+    d.rng_cnt[lane] += 2ull * trng.used;
+    d.buf_head[lane] = buf.head;
+    d.buf_len[lane] = buf.len;
     d.has_new[lane] = hn;
     if (hn) store_rec(d.newt + lane, nt);
 }
@@ -370,8 +555,7 @@ __global__ void k_reset(EcDev d) {
     if (lane >= d.P) return;
     d.has_new[lane] = 0;
     d.buf_head[lane] = d.buf_len[lane] = 0;
-    d.wq_head[lane] = d.wq_len[lane] = 0;
-    d.wq_min[lane] = NEVER;
+    d.wq_len[lane] = 0;
     d.ex_n[lane] = 0;
     for (int s = 0; s < d.D; s++) {
         d.rq_head[(size_t)s * d.P + lane] = 0;
@@ -384,16 +568,17 @@ __global__ void k_reset(EcDev d) {
     }
 }
 
-// Shared tail: observation + availability mask of the current state for the envs of this block
-// (edge_node.py:109-136,179-197).  s_wql/s_hasnew/s_any are [blockDim] LDS scratch, s_obs [blockDim*9].
-__device__ void observe_block(const EcDev& d, const LaneId& L, u32 wq_head, u32 wq_len, u32 has_new, const Rec& newt,
-                              float* __restrict__ obs, int32_t* __restrict__ avail, u32* s_wql, u32* s_hasnew,
-                              u32* s_any, float* s_obs) {
+// Observation + availability mask for the envs of this block (edge_node.py:109-136,179-197).
+// Per lane in: wq_len, `wait_sum` = get_waiting_time() (fp64, queue order), has_new/newt.
+// LDS scratch: s_full/s_hasnew/s_any [NT] (NT = active lanes), s_obs [NT*9].
+__device__ __forceinline__ void observe_block(const EcDev& d, const LaneId& L, u32 wq_len, double wait_sum, u32 has_new,
+                                              const Rec& newt, float* __restrict__ obs, int32_t* __restrict__ avail,
+                                              u32* s_full, u32* s_hasnew, u32* s_any, float* s_obs) {
     const int N = d.N, A = d.A;
     const int tid = threadIdx.x;
-    const int epb = blockDim.x / N;
+    const int epb = d.epb;
     if (L.valid) {
-        s_wql[tid] = ((double)wq_len >= d.qthr[L.node]) ? 1u : 0u;  // "full" flag, edge_node.py:186-188
+        s_full[tid] = ((double)wq_len >= d.qthr[L.node]) ? 1u : 0u;  // edge_node.py:186-188
         s_hasnew[tid] = has_new;
         if (obs) {
             float* o = s_obs + tid * 9;
@@ -401,17 +586,11 @@ __device__ void observe_block(const EcDev& d, const LaneId& L, u32 wq_head, u32 
             o[1] = d.obs_const[L.node * 3 + 1];
             o[2] = d.obs_const[L.node * 3 + 2];
             o[3] = (float)ddiv((double)wq_len, d.qlen[L.node]);
-            double w = 0.0;  // get_waiting_time, edge_node.py:99-104 (cet == 0 for waiting tasks)
-            u32 pos = wq_head;
-            for (u32 j = 0; j < wq_len; j++) {
-                w = dadd(w, d.wq[(size_t)pos * d.P + L.lane].et);
-                pos = pos + 1 == (u32)d.capW ? 0u : pos + 1;
-            }
-            o[4] = (float)ddiv(w, d.deadline);
+            o[4] = (float)ddiv(wait_sum, d.deadline);
             if (has_new) {
                 o[5] = (float)ddiv(newt.size, d.obs_size_norm);
                 o[6] = (float)ddiv(newt.cycles, d.obs_cyc_norm);
-                o[7] = (float)ddiv(d.deadline, d.deadline);
+                o[7] = 1.0f;  // task_deadline / deadline (edge_node.py:130): the same number over itself
                 o[8] = (float)newt.hop;
             } else {
                 o[5] = o[6] = o[7] = -1.0f;
@@ -420,24 +599,31 @@ __device__ void observe_block(const EcDev& d, const LaneId& L, u32 wq_head, u32 
         }
     }
     __syncthreads();
+    const int64_t env0 = (int64_t)blockIdx.x * epb;
+    const int64_t nenv = (d.B - env0) < epb ? (d.B - env0) : epb;
     if (avail) {
         if (L.valid) {
+            // any adjacent (or own) queue with room?  adj rows are bit masks when N <= 64
             u32 any = 0;
-            const u32* full = s_wql + L.env_local * N;
-            for (int j = 0; j < N; j++) any |= (d.adj[L.node * A + j] && !full[j]) ? 1u : 0u;
+            const u32* full = s_full + L.env_local * N;
+            if (d.adj_bits) {
+                const u64 row = d.adj_bits[L.node];
+                for (int j = 0; j < N; j++) any |= (((row >> j) & 1ull) && !full[j]) ? 1u : 0u;
+            } else {
+                for (int j = 0; j < N; j++) any |= (d.adj[L.node * A + j] && !full[j]) ? 1u : 0u;
+            }
             s_any[tid] = any;
         }
         __syncthreads();
-        const int64_t env0 = (int64_t)blockIdx.x * epb;
-        const int64_t nenv = (d.B - env0) < epb ? (d.B - env0) : epb;
         const int total = (int)nenv * N * A;
         int32_t* out = avail + env0 * N * A;
         for (int idx = tid; idx < total; idx += blockDim.x) {
-            const int t = idx / A, j = idx - t * A;  // t = env_local*N + node
-            const int el = t / N, i = t - el * N;
+            const int t = (int)fdiv((u32)idx, d.divA), j = idx - t * A;  // t = env_local*N + node
+            const int el = (int)fdiv((u32)t, d.divN), i = t - el * N;
             int v;
             if (s_hasnew[t]) {
-                v = (j < N) ? ((d.adj[i * A + j] && !s_wql[el * N + j]) || (!s_any[t] && j == i)) : 0;
+                const bool adjacent = d.adj_bits ? ((d.adj_bits[i] >> j) & 1ull) : (j < N && d.adj[i * A + j]);
+                v = (j < N) ? ((adjacent && !s_full[el * N + j]) || (!s_any[t] && j == i)) : 0;
             } else {
                 v = (j == N);
             }
@@ -445,8 +631,6 @@ __device__ void observe_block(const EcDev& d, const LaneId& L, u32 wq_head, u32 
         }
     }
     if (obs) {
-        const int64_t env0 = (int64_t)blockIdx.x * epb;
-        const int64_t nenv = (d.B - env0) < epb ? (d.B - env0) : epb;
         const int total = (int)nenv * N * 9;
         float* out = obs + env0 * N * 9;
         for (int idx = tid; idx < total; idx += blockDim.x) out[idx] = s_obs[idx];
@@ -455,336 +639,625 @@ __device__ void observe_block(const EcDev& d, const LaneId& L, u32 wq_head, u32 
 
 __global__ void k_observe(EcDev d, float* __restrict__ obs, int32_t* __restrict__ avail) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int NT = blockDim.x;
-    u32* s_wql = reinterpret_cast<u32*>(smem);
-    u32* s_hasnew = s_wql + NT;
+    const int NT = d.epb * d.N;  // active lanes
+    u32* s_full = reinterpret_cast<u32*>(smem);
+    u32* s_hasnew = s_full + NT;
     u32* s_any = s_hasnew + NT;
     float* s_obs = reinterpret_cast<float*>(s_any + NT);
     const LaneId L = lane_id(d);
-    u32 wq_head = 0, wq_len = 0, has_new = 0;
+    u32 wq_len = 0, has_new = 0;
+    double w = 0.0;
     Rec newt;
     newt.size = newt.cycles = 0;
     newt.hop = 0;
     if (L.valid) {
-        wq_head = d.wq_head[L.lane];
         wq_len = d.wq_len[L.lane];
         has_new = d.has_new[L.lane];
         if (has_new) newt = load_rec(d.newt + L.lane);
+        // get_waiting_time, edge_node.py:99-104 (current_execute_time is 0 for every waiting task)
+        for (u32 j = 0; j < wq_len; j++) w = dadd(w, d.wqe[(size_t)j * d.P + L.lane]);
     }
-    observe_block(d, L, wq_head, wq_len, has_new, newt, obs, avail, s_wql, s_hasnew, s_any, s_obs);
+    observe_block(d, L, wq_len, w, has_new, newt, obs, avail, s_full, s_hasnew, s_any, s_obs);
 }
 
+// LDS carve-up of k_step; all per-lane arrays are [slot][NT], NT = active lanes of the block
+struct StepLds {
+    double* acc;     // [ACC_LDS]
+    uint4* wqm;      // [capW][NT]
+    double* wqe;     // [capW][NT]
+    u64* exC;        // [KMAX][NT] {ewt, twt, ctt, bwt} of the executing tasks (kept for ec_debug_dump)
+    uint4* rqrec;    // [DMAX][2][NT] head record of each receiving queue
+    u32* rqhs;       // [DMAX][NT]
+    u32* rqhead;     // [DMAX][NT]
+    u32* rqdirty;    // [DMAX][NT] head record exists only in LDS
+    u32* rqlen;      // [DMAX][NT] staging / hand-off copy of the queue length
+    u32* rqarr;      // [DMAX][NT] staging / hand-off copy of the head's arrival tick
+    u32* fa;         // [RB_FAIL][NT] failure-stream window (aliased by the observation scratch afterwards)
+    double* rew;     // [NT]
+    double* ct;      // [NT]
+    u32* cnt;        // [4][NT]
+};
+__host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int capW) {
+    size_t b = 0;
+    b += sizeof(double) * ACC_LDS;
+    b += (size_t)NT * capW * (16 + 8);
+    b += (size_t)NT * KMAX * 8;
+    b += (size_t)NT * DMAX * (32 + 5 * 4);
+    b += (size_t)NT * RB_FAIL * 4;
+    b += (size_t)NT * (8 + 8 + 16);
+    return b + 64;
+}
+
+constexpr u32 KIND_SUCCESS = 1u << 16;
+
 // EdgeComputingEnv.step (edge_computing_env.py:84-143) for the envs of this block.
-__global__ void k_step(EcDev d, const int64_t* __restrict__ actions, float* __restrict__ reward,
-                       uint8_t* __restrict__ terminated, int32_t* __restrict__ counters,
-                       float* __restrict__ completion_time, float* __restrict__ next_obs,
-                       int32_t* __restrict__ next_avail) {
+// KMAX >= k and DMAX >= max in-degree are compile-time so that the executing slots and the receiving-queue
+// scalars live in registers and the per-mini-slot work is branch-free except for events.
+template <int KMAX, int DMAX>
+__global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict__ actions, float* __restrict__ reward,
+                                              uint8_t* __restrict__ terminated, int32_t* __restrict__ counters,
+                                              float* __restrict__ completion_time, float* __restrict__ next_obs,
+                                              int32_t* __restrict__ next_avail) {
+    static_assert(RB_FAIL >= KMAX + DMAX, "failure window too small");
+    static_assert(RB_FAIL * 4 >= 12 + 36, "observation scratch does not fit the failure window");
     extern __shared__ __align__(16) unsigned char smem[];
-    const int NT = blockDim.x;
+    const int NT = d.epb * d.N;  // active lanes of the block = stride of the per-lane LDS arrays
     const int tid = threadIdx.x;
-    // LDS carve-up (all [slot][thread])
-    u64* s_exA = reinterpret_cast<u64*>(smem);            // [k][NT]
-    u64* s_exB = s_exA + (size_t)d.k * NT;                 // [k][NT]
-    double* s_rew = reinterpret_cast<double*>(s_exB + (size_t)d.k * NT);  // [NT]
-    double* s_ct = s_rew + NT;                             // [NT]
-    u32* s_rqlen = reinterpret_cast<u32*>(s_ct + NT);      // [D][NT]
-    u32* s_rqarr = s_rqlen + (size_t)d.D * NT;             // [D][NT]
-    u32* s_cnt = s_rqarr + (size_t)d.D * NT;               // [4][NT]
-    u32* s_wql = s_cnt + 4 * NT;                           // [NT]
-    u32* s_hasnew = s_wql + NT;
-    u32* s_any = s_hasnew + NT;
-    float* s_obs = reinterpret_cast<float*>(s_any + NT);   // [NT*9]
+    const int N = d.N, D = d.D;
+    const int64_t P = d.P;
+    const u32 wmask = (u32)d.capW - 1;  // capW is a power of two
+
+    StepLds S;
+    {
+        unsigned char* p = smem;
+        S.wqm = reinterpret_cast<uint4*>(p);     p += (size_t)NT * d.capW * 16;
+        S.rqrec = reinterpret_cast<uint4*>(p);   p += (size_t)NT * DMAX * 32;
+        S.acc = reinterpret_cast<double*>(p);    p += sizeof(double) * ACC_LDS;
+        S.wqe = reinterpret_cast<double*>(p);    p += (size_t)NT * d.capW * 8;
+        S.exC = reinterpret_cast<u64*>(p);       p += (size_t)NT * KMAX * 8;
+        S.rew = reinterpret_cast<double*>(p);    p += (size_t)NT * 8;
+        S.ct = reinterpret_cast<double*>(p);     p += (size_t)NT * 8;
+        S.fa = reinterpret_cast<u32*>(p);        p += (size_t)NT * RB_FAIL * 4;
+        S.rqhs = reinterpret_cast<u32*>(p);      p += (size_t)NT * DMAX * 4;
+        S.rqhead = reinterpret_cast<u32*>(p);    p += (size_t)NT * DMAX * 4;
+        S.rqdirty = reinterpret_cast<u32*>(p);   p += (size_t)NT * DMAX * 4;
+        S.rqlen = reinterpret_cast<u32*>(p);     p += (size_t)NT * DMAX * 4;
+        S.rqarr = reinterpret_cast<u32*>(p);     p += (size_t)NT * DMAX * 4;
+        S.cnt = reinterpret_cast<u32*>(p);       p += (size_t)NT * 16;
+    }
+    Lut lut{d, S.acc, 0u};
+
+    {  // block-shared low part of the tick LUT
+        const int nacc = d.maxTicks + 1 < ACC_LDS ? d.maxTicks + 1 : ACC_LDS;
+        for (int i = tid; i < nacc; i += blockDim.x) S.acc[i] = d.acc[i];
+    }
 
     const LaneId L = lane_id(d);
-    const int N = d.N;
-    const int64_t P = d.P;
     const int64_t lane = L.lane;
     const int node = L.node;
 
-    u32 c0 = 0;  // index of the first execute/receive call of this step
-    u32 has_new = 0, n_off = 0;
+    // ---------------------------------------------------------------- stage the lane's working set
+    u32 c0 = 0, has_new = 0, n_off = 0, ex_n = 0, wq_h = 0, wq_len = 0, wq_min = NEVER, ovf = 0;
+    bool wq_dirty = false;
+    int deg = 0;
+    int64_t action = N;
+    u32 exA_thr = 0, exB_thr = 0;          // execution failure threshold M = A << 26 | B
+    u32 lkA[DMAX], lkB[DMAX];              // per in-link transmission failure thresholds
+    double cap = 1.0, rate = 0.0, bin_qn = 0.0, bin_px2 = 0.0;
+    u32 bin_flip = 0;
+    int slot = -1;
     Rec newt;
     newt.size = newt.cycles = 0;
     newt.twt = newt.ctt = newt.hop = newt.ntx = 0;
     newt.bwt = 0;
     newt.enq = 0;
-
-    // ---------------------------------------------------------------- phase A: offload_task, edge_node.py:199-234
+    Buffer buf;
+    buf.head = buf.len = 0;
+    buf.head_rec = newt;
+    RngFail frng;
+    RngTask trng;
+    // executing slots: exw = cet | fin << 16 (fin: the cet at which the task drops or completes),
+    // exh = hop | KIND_SUCCESS, exT = the reference's task_time at cet == fin
+    u32 exw[KMAX], exh[KMAX];
+    double exT[KMAX];
+    u32 rql[DMAX], rqa[DMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; s++) {
+        exw[s] = exh[s] = 0;
+        exT[s] = 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < DMAX; s++) {
+        rql[s] = 0;
+        rqa[s] = NEVER;
+        lkA[s] = 0xffffffffu;
+        lkB[s] = 0;
+    }
     if (L.valid) {
         c0 = d.tick[L.env];
         has_new = d.has_new[lane];
         n_off = d.n_off[lane];
-        const int64_t action = actions[lane];
-        if (has_new && action != N) {
-            newt = load_rec(d.newt + lane);
-            if (action == node) {
-                // local: execution_queue.append(task)
-                n_off++;
-                WRec w;
-                w.et = ddiv(newt.cycles, d.cap[node]);
-                w.enq = c0;
-                w.nexec = (u16)ticks_to_reach(d, w.et);
-                w.twt = newt.twt;
-                w.ctt = newt.ctt;
-                w.bwt = (u16)clamp16(d, (u32)newt.bwt);
-                w.hop = newt.hop;
-                w.pad[0] = w.pad[1] = w.pad[2] = 0;
-                const u32 nd = deadline_ticks(d, 0, 0, w.twt, w.ctt, w.bwt);
-                w.drop_at = nd == T16_NEVER ? NEVER : c0 + nd - 1;
-                u32 wl = d.wq_len[lane], wh = d.wq_head[lane];
-                if (wl >= (u32)d.capW) {
-                    flag(d, EC_ST_WAIT_OVERFLOW);
-                } else {
-                    u32 pos = wh + wl;
-                    if (pos >= (u32)d.capW) pos -= d.capW;
-                    store_rec(d.wq + (size_t)pos * P + lane, w);
-                    d.wq_len[lane] = wl + 1;
-                    const u32 m = d.wq_min[lane];
-                    if (wl == 0 || w.drop_at < m) d.wq_min[lane] = w.drop_at;
-                }
-            } else {
-                const int slot = (action >= 0 && action < N) ? d.slot_of[node * N + (int)action] : -1;
-                if (slot < 0) {
-                    flag(d, EC_ST_BAD_ACTION);  // reference: ZeroDivisionError at edge_node.py:227
-                } else {
-                    n_off++;
-                    const int64_t dst = L.env * N + action;
-                    Rec r = newt;
-                    const double tt = ddiv(r.size, d.rate[node * N + (int)action]);
-                    r.ntx = (u16)ticks_to_reach(d, tt);
-                    r.hop = (u16)(r.hop + 1);
-                    r.enq = c0;
-                    const size_t so = (size_t)slot * P + dst;
-                    const u32 ql = d.rq_len[so], qh = d.rq_head[so];
-                    if (ql >= (u32)d.capR) {
-                        flag(d, EC_ST_RECV_OVERFLOW);
-                    } else {
-                        u32 pos = qh + ql;
-                        if (pos >= (u32)d.capR) pos -= d.capR;
-                        store_rec(d.rq + ((size_t)slot * d.capR + pos) * P + dst, r);
-                        d.rq_len[so] = ql + 1;
-                        if (ql == 0) {
-                            d.rq_hstart[so] = c0;
-                            const u32 need = r.ntx == T16_NEVER ? NEVER : (r.ntx > (u32)r.ctt + 1 ? r.ntx - r.ctt - 1 : 0u);
-                            d.rq_arrive[so] = need == NEVER ? NEVER : c0 + need;
-                        }
-                    }
+        action = actions[lane];
+        buf.head = d.buf_head[lane];
+        buf.len = d.buf_len[lane];
+        wq_len = d.wq_len[lane];
+        ex_n = d.ex_n[lane];
+        deg = d.deg[node];
+        const u64 me = d.thr_exec_m[node];
+        exA_thr = (u32)(me >> 26);
+        exB_thr = (u32)(me & 0x3ffffffull);
+        cap = d.cap[node];
+        bin_qn = d.bin_qn[node];
+        bin_px2 = d.bin_px2[node];
+        bin_flip = d.bin_flip[node];
+        const u32 tpos = d.rng_pos[lane], tahead = d.rng_ahead[lane];
+        if (has_new) newt = load_rec(d.newt + lane);
+        if (buf.len > 0) buf.head_rec = load_rec(d.buf + (size_t)buf.head * P + lane);
+        if (has_new && action >= 0 && action < N && action != node) {
+            slot = d.slot_of[node * N + (int)action];
+            rate = d.rate[node * N + (int)action];
+        }
+        for (u32 j = 0; j < wq_len; j++) {
+            const uint4 m = d.wqm[(size_t)j * P + lane];
+            S.wqm[j * NT + tid] = m;
+            S.wqe[j * NT + tid] = d.wqe[(size_t)j * P + lane];
+            const u32 da = wmeta_drop_at(m);
+            wq_min = da < wq_min ? da : wq_min;
+        }
+#pragma unroll
+        for (int s = 0; s < KMAX; s++) {
+            if ((u32)s < ex_n) {
+                const u64 a = d.exA[(size_t)s * P + lane];
+                exw[s] = (u32)a;
+                exh[s] = (u32)(a >> 32);
+                exT[s] = d.exB[(size_t)s * P + lane];
+                S.exC[s * NT + tid] = d.exC[(size_t)s * P + lane];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < DMAX; s++) {
+            if (s < deg) {
+                const size_t so = (size_t)s * P + lane;
+                const u32 ql = d.rq_len[so], qh = d.rq_head[so];
+                S.rqlen[s * NT + tid] = ql;
+                S.rqarr[s * NT + tid] = d.rq_arrive[so];
+                S.rqhead[s * NT + tid] = qh;
+                S.rqhs[s * NT + tid] = d.rq_hstart[so];
+                S.rqdirty[s * NT + tid] = 0;
+                const u64 ml = d.thr_link_m[node * D + s];
+                lkA[s] = (u32)(ml >> 26);
+                lkB[s] = (u32)(ml & 0x3ffffffull);
+                if (ql > 0) {
+                    const uint4* q = reinterpret_cast<const uint4*>(d.rq + ((size_t)s * d.capR + qh) * P + lane);
+                    S.rqrec[(s * 2 + 0) * NT + tid] = q[0];
+                    S.rqrec[(s * 2 + 1) * NT + tid] = q[1];
                 }
             }
         }
+#ifdef ABL_NO_TRNG
+        trng.mt = d.mt + (size_t)lane * MT_N; trng.pos = tpos; trng.ahead = 8; trng.idx = 0; trng.used = 0;
+        for (int i = 0; i < RB_TASK; i++) trng.u[i] = 0.3 + 0.1 * i;
+#else
+        trng.open(d.mt + (size_t)lane * MT_N, tpos, tahead);
+#endif
     }
-    __syncthreads();  // receiving-queue pushes of this env are visible to their destination lanes
+    __syncthreads();
 
-    // ---------------------------------------------------------------- load the per-lane working set
-    u32 ex_n = 0, wq_head = 0, wq_len = 0, wq_min = NEVER, buf_head = 0, buf_len = 0;
-    int deg = 0;
-    double rew = 0.0, ct = 0.0;
-    u32 n_fail = 0, n_drop = 0, n_fin = 0, n_succ = 0;
-    Rng frng{nullptr, 0, 0}, trng{nullptr, 0, 0};
-    double thr_exec = 0.0;
+    // ---------------------------------------------------------------- phase A: offload_task, edge_node.py:199-234
+    if (L.valid && has_new && action != N) {
+        if (action == node) {
+            // local: execution_queue.append(task)
+            n_off++;
+            const double et = ddiv(newt.cycles, cap);
+            WMeta m;
+            m.enq = c0;
+            m.nexec = lut.ticks_to_reach(et);
+            m.twt = newt.twt;
+            m.ctt = newt.ctt;
+            m.bwt = sat16((u32)newt.bwt, ovf);
+            m.hop = newt.hop;
+            double unused;
+            m.nd = lut.deadline_ticks(0, 0, m.twt, m.ctt, m.bwt, &unused);
+            if (wq_len >= (u32)d.capW) {
+                flag(d, EC_ST_WAIT_OVERFLOW);
+            } else {
+                const u32 pos = (wq_h + wq_len) & wmask;
+                const uint4 pm = wmeta_pack(m);
+                S.wqm[pos * NT + tid] = pm;
+                S.wqe[pos * NT + tid] = et;
+                wq_len++;
+                wq_dirty = true;
+                const u32 da = wmeta_drop_at(pm);
+                wq_min = da < wq_min ? da : wq_min;
+            }
+        } else if (slot < 0) {
+            flag(d, EC_ST_BAD_ACTION);  // reference: ZeroDivisionError at edge_node.py:227
+        } else {
+            n_off++;
+            const int dt_ = L.env_local * N + (int)action;  // destination lane's thread index in this block
+            const int64_t dst = L.env * N + action;
+            Rec r = newt;
+            const double tt = ddiv(r.size, rate);
+            r.ntx = (u16)lut.ticks_to_reach(tt);
+            r.hop = (u16)(r.hop + 1);
+            r.enq = c0;
+            // receiving_queues[self.id] of the destination has this lane as its only producer
+            const u32 ql = S.rqlen[slot * NT + dt_], qh = S.rqhead[slot * NT + dt_];
+            if (ql >= (u32)d.capR) {
+                flag(d, EC_ST_RECV_OVERFLOW);
+            } else {
+                if (ql == 0) {
+                    union {
+                        Rec r;
+                        uint4 v[2];
+                    } u;
+                    u.r = r;
+                    S.rqrec[(slot * 2 + 0) * NT + dt_] = u.v[0];
+                    S.rqrec[(slot * 2 + 1) * NT + dt_] = u.v[1];
+                    S.rqdirty[slot * NT + dt_] = 1;
+                    S.rqhs[slot * NT + dt_] = c0;
+                    S.rqarr[slot * NT + dt_] = arrive_at(c0, r.ntx, r.ctt);
+                } else {
+                    u32 pos = qh + ql;
+                    if (pos >= (u32)d.capR) pos -= d.capR;
+                    store_rec(d.rq + ((size_t)slot * d.capR + pos) * P + dst, r);
+                }
+                S.rqlen[slot * NT + dt_] = ql + 1;
+            }
+        }
+    }
+    __syncthreads();  // pushes into the LDS queue heads are visible to their destination lanes
+
+    // ---------------------------------------------------------------- failure-stream window
+    // Within a step no queue gains a task after phase A, so this bounds the lane's draws: per mini-slot at most
+    // min(k, executing + waiting) execution draws and one draw per non-empty receiving queue.
+    u32 draw_bound = 0;
     if (L.valid) {
-        ex_n = d.ex_n[lane];
-        wq_head = d.wq_head[lane];
-        wq_len = d.wq_len[lane];
-        wq_min = d.wq_min[lane];
-        buf_head = d.buf_head[lane];
-        buf_len = d.buf_len[lane];
-        deg = d.deg[node];
-        thr_exec = d.thr_exec[node];
-        trng = Rng{d.mt + (size_t)lane * MT_N, d.rng_pos[lane], 0};
-        frng = Rng{d.mt + ((size_t)P + lane) * MT_N, d.rng_pos[P + lane], 0};
-        for (u32 s = 0; s < ex_n; s++) {
-            s_exA[s * NT + tid] = d.exA[(size_t)s * P + lane];
-            s_exB[s * NT + tid] = d.exB[(size_t)s * P + lane];
+        u32 n_ne = 0;
+#pragma unroll
+        for (int s = 0; s < DMAX; s++) {
+            if (s < deg) {
+                rql[s] = S.rqlen[s * NT + tid];
+                rqa[s] = S.rqarr[s * NT + tid];
+                n_ne += rql[s] > 0 ? 1u : 0u;
+            }
         }
-        for (int s = 0; s < deg; s++) {
-            s_rqlen[s * NT + tid] = d.rq_len[(size_t)s * P + lane];
-            s_rqarr[s * NT + tid] = d.rq_arrive[(size_t)s * P + lane];
-        }
+        const u32 n_ex = ex_n + wq_len < (u32)d.k ? ex_n + wq_len : (u32)d.k;
+        draw_bound = (u32)d.S * (n_ex + n_ne);
+#ifdef ABL_NO_FRNG
+        frng.open(d.mt + ((size_t)P + lane) * MT_N, d.rng_pos[P + lane], d.rng_ahead[P + lane], S.fa + tid, NT, 0);
+        frng.staged = RB_FAIL;
+        draw_bound = 0;
+#else
+        frng.open(d.mt + ((size_t)P + lane) * MT_N, d.rng_pos[P + lane], d.rng_ahead[P + lane], S.fa + tid, NT,
+                  draw_bound < (u32)RB_FAIL ? draw_bound : (u32)RB_FAIL);
+#endif
     }
 
     // ---------------------------------------------------------------- phase B: mini-slots, edge_computing_env.py:101-105
+    double rew = 0.0, ct = 0.0;
+    u32 n_fail = 0, n_drop = 0, n_fin = 0, n_succ = 0;
     if (L.valid) {
+#ifdef ABL_TICKS
+        for (int ms = 0; ms < ABL_TICKS; ms++) {
+#else
         for (int ms = 0; ms < d.S; ms++) {
+#endif
             const u32 c = c0 + (u32)ms;
             // ---- execute_task, edge_node.py:236-309
             // (i) admit heads of the waiting queue while a slot is free (:238-241)
             while (ex_n < (u32)d.k && wq_len > 0) {
-                const WRec w = load_rec(d.wq + (size_t)wq_head * P + lane);
-                wq_head = wq_head + 1 == (u32)d.capW ? 0u : wq_head + 1;
+                const WMeta w = wmeta_unpack(S.wqm[wq_h * NT + tid]);
+                wq_h = (wq_h + 1) & wmask;
                 wq_len--;
-                const u32 ewt = clamp16(d, c - w.enq);
-                const u32 dc = deadline_ticks(d, 1, ewt, w.twt, w.ctt, w.bwt);
-                s_exA[ex_n * NT + tid] = pack4(0, dc, w.nexec, w.hop);
-                s_exB[ex_n * NT + tid] = pack4(ewt, w.twt, w.ctt, w.bwt);
+                wq_dirty = true;
+                const u32 ewt = sat16(c - w.enq, ovf);
+                double Td;
+                const u32 dc = lut.deadline_ticks(1, ewt, w.twt, w.ctt, w.bwt, &Td);
+                // the drop test precedes the completion test (:268,278): a tie is a drop
+                const bool succ = w.nexec < dc;
+                const u32 fin = succ ? w.nexec : dc;
+                const double T = succ ? lut.task_time(ewt, fin, w.twt, w.ctt, w.bwt) : Td;
+                const u32 nw = fin << 16, nh = w.hop | (succ ? KIND_SUCCESS : 0u);
+#pragma unroll
+                for (int s = 0; s < KMAX; s++) {
+                    if ((u32)s == ex_n) {
+                        exw[s] = nw;
+                        exh[s] = nh;
+                        exT[s] = T;
+                    }
+                }
+                S.exC[ex_n * NT + tid] = pack4(ewt, w.twt, w.ctt, w.bwt);
                 ex_n++;
             }
             if (wq_len == 0) wq_min = NEVER;
-            // (ii) is implicit: waiting time is c - enq.  (iii) the executing tasks, in order (:252-296)
+
+            // the draws of this mini-slot: one per executing task, then one per non-empty receiving queue
+            u32 n_ne = 0;
+#pragma unroll
+            for (int s = 0; s < DMAX; s++) n_ne += rql[s] > 0 ? 1u : 0u;
+            if (frng.idx + ex_n + n_ne > frng.staged) {
+                const u32 left = draw_bound - (frng.used + frng.idx);  // the bound only shrinks as draws are spent
+                frng.restage(left < (u32)RB_FAIL ? left : (u32)RB_FAIL);
+            }
+            u32 ae[KMAX], ar[DMAX], ir[DMAX];
+            const u32 base = frng.idx;
             {
-                u32 w = 0;
-                for (u32 s = 0; s < ex_n; s++) {
-                    const u64 a = s_exA[s * NT + tid];
-                    const u32 cet = f16(a, 0) + 1;
-                    const double u = rng_double(frng);
-                    bool done = true;
-                    if (u > thr_exec) {
-                        rew = dadd(rew, d.pen_fail);
-                        n_fail++;
-                        n_fin++;
-                    } else if (cet >= f16(a, 1)) {
-                        const u64 b = s_exB[s * NT + tid];
-                        rew = dadd(rew, d.pen_drop);
-                        n_drop++;
-                        n_fin++;
-                        ct = dadd(ct, task_time(d, f16(b, 0), cet, f16(b, 1), f16(b, 2), f16(b, 3)));
-                    } else if (cet >= f16(a, 2)) {
-                        const u64 b = s_exB[s * NT + tid];
-                        const u32 hop = f16(a, 3);
-                        rew = dadd(rew, d.rew_succ);
-                        rew = dadd(rew, hop > 1 ? dmul(d.pen_hop, (double)(hop - 1)) : 0.0);
-                        n_succ++;
-                        n_fin++;
-                        ct = dadd(ct, task_time(d, f16(b, 0), cet, f16(b, 1), f16(b, 2), f16(b, 3)));
+#pragma unroll
+                for (int s = 0; s < KMAX; s++) {
+                    const u32 i = base + s;
+                    ae[s] = frng.buf[(i < (u32)RB_FAIL ? i : (u32)RB_FAIL - 1) * NT];
+                }
+                u32 r = base + ex_n;
+#pragma unroll
+                for (int s = 0; s < DMAX; s++) {
+                    ir[s] = r;
+                    ar[s] = frng.buf[(r < (u32)RB_FAIL ? r : (u32)RB_FAIL - 1) * NT];
+                    r += rql[s] > 0 ? 1u : 0u;
+                }
+                frng.idx = r;
+            }
+
+            // (ii) is implicit: waiting time is c - enq.  (iii) the executing tasks, in order (:252-296)
+            u32 keep = 0;
+            {
+                const u32 n0 = ex_n;
+#pragma unroll
+                for (int s = 0; s < KMAX; s++) {
+                    const bool act = (u32)s < n0;
+                    const u32 cet = (exw[s] & 0xffffu) + 1;
+                    const u32 fin = exw[s] >> 16;
+                    bool fail = act && ae[s] > exA_thr;
+                    if (act && ae[s] == exA_thr) fail = frng.b_of(base + s) > exB_thr;  // 2^-27 tie on the first word
+                    const bool done = act && !fail && cet >= fin;
+                    const bool succ = done && (exh[s] & KIND_SUCCESS);
+                    const bool drop = done && !succ;
+                    const u32 hop = exh[s] & 0xffffu;
+                    rew = fail ? dadd(rew, d.pen_fail) : rew;
+                    rew = drop ? dadd(rew, d.pen_drop) : rew;
+                    rew = succ ? dadd(rew, d.rew_succ) : rew;
+                    rew = succ ? dadd(rew, hop > 1 ? dmul(d.pen_hop, (double)(hop - 1)) : 0.0) : rew;
+                    ct = done ? dadd(ct, exT[s]) : ct;
+                    n_fail += fail;
+                    n_drop += drop;
+                    n_succ += succ;
+                    n_fin += (fail || done);
+                    if (succ) {
                         u32 bin = hop;
                         if (bin >= (u32)d.H) {
                             bin = d.H - 1;
                             flag(d, EC_ST_HOP_OVERFLOW);
                         }
                         atomicAdd(d.hop_hist + L.env * d.H + bin, 1);
-                    } else {
-                        done = false;
                     }
-                    if (!done) {
-                        s_exA[w * NT + tid] = (a & ~0xffffull) | (u64)clamp16(d, cet);
-                        if (w != s) s_exB[w * NT + tid] = s_exB[s * NT + tid];
-                        w++;
-                    }
+                    const bool kp = act && !fail && !done;
+                    exw[s] = kp ? ((exw[s] & 0xffff0000u) | (cet > 0xfffeu ? 0xfffeu : cet)) : exw[s];
+                    keep |= kp ? (1u << s) : 0u;
                 }
-                ex_n = w;
+                if (keep != ((1u << n0) - 1)) {
+                    // stable compaction of the survivors (executing_queue.remove keeps the order)
+                    u32 nw[KMAX], nh[KMAX];
+                    double nT[KMAX];
+#pragma unroll
+                    for (int w = 0; w < KMAX; w++) {
+                        nw[w] = 0;
+                        nh[w] = 0;
+                        nT[w] = 0.0;
+                    }
+                    u32 cnt = 0;
+#pragma unroll
+                    for (int s = 0; s < KMAX; s++) {
+                        const bool kp = (keep >> s) & 1u;
+#pragma unroll
+                        for (int w = 0; w <= s; w++) {
+                            const bool hit = kp && cnt == (u32)w;
+                            nw[w] = hit ? exw[s] : nw[w];
+                            nh[w] = hit ? exh[s] : nh[w];
+                            nT[w] = hit ? exT[s] : nT[w];
+                        }
+                        if (kp && cnt != (u32)s) S.exC[cnt * NT + tid] = S.exC[s * NT + tid];
+                        cnt += kp ? 1u : 0u;
+                    }
+#pragma unroll
+                    for (int w = 0; w < KMAX; w++) {
+                        exw[w] = nw[w];
+                        exh[w] = nh[w];
+                        exT[w] = nT[w];
+                    }
+                    ex_n = cnt;
+                }
             }
-            // (iv) deadline sweep of the waiting queue (:299-309), only when some drop_at has come due
+            // (iv) deadline sweep of the waiting queue (:299-309), only when some drop has come due
             if (wq_len > 0 && wq_min <= c) {
-                u32 rd = wq_head, wr = wq_head, kept = 0, newmin = NEVER;
+                u32 rd = wq_h, wr = wq_h, kept = 0, newmin = NEVER;
                 for (u32 j = 0; j < wq_len; j++) {
-                    const WRec w = load_rec(d.wq + (size_t)rd * P + lane);
-                    if (w.drop_at <= c) {
+                    const uint4 pm = S.wqm[rd * NT + tid];
+                    const u32 da = wmeta_drop_at(pm);
+                    if (da <= c) {
+                        const WMeta w = wmeta_unpack(pm);
                         n_drop++;
                         n_fin++;
                         rew = dadd(rew, d.pen_drop);
-                        ct = dadd(ct, task_time(d, c - w.enq + 1, 0, w.twt, w.ctt, w.bwt));
+                        ct = dadd(ct, lut.task_time(c - w.enq + 1, 0, w.twt, w.ctt, w.bwt));
                     } else {
-                        if (wr != rd) store_rec(d.wq + (size_t)wr * P + lane, w);
-                        wr = wr + 1 == (u32)d.capW ? 0u : wr + 1;
+                        if (wr != rd) {
+                            S.wqm[wr * NT + tid] = pm;
+                            S.wqe[wr * NT + tid] = S.wqe[rd * NT + tid];
+                        }
+                        wr = (wr + 1) & wmask;
                         kept++;
-                        newmin = w.drop_at < newmin ? w.drop_at : newmin;
+                        newmin = da < newmin ? da : newmin;
                     }
-                    rd = rd + 1 == (u32)d.capW ? 0u : rd + 1;
+                    rd = (rd + 1) & wmask;
                 }
                 wq_len = kept;
                 wq_min = newmin;
+                wq_dirty = true;
             }
             // ---- receive_task, edge_node.py:311-333: in-neighbours in ascending source order
-            for (int s = 0; s < deg; s++) {
-                u32 ql = s_rqlen[s * NT + tid];
-                if (ql == 0) continue;
-                const double u = rng_double(frng);
-                const bool failed = u > d.thr_link[node * d.D + s];
-                const bool arrived = !failed && c >= s_rqarr[s * NT + tid];
-                if (!failed && !arrived) continue;
-                const size_t so = (size_t)s * P + lane;
-                u32 qh = d.rq_head[so];
-                if (failed) {
-                    n_fail++;
-                    n_fin++;
-                    rew = dadd(rew, d.pen_fail);
-                } else {
-                    Rec r = load_rec(d.rq + ((size_t)s * d.capR + qh) * P + lane);
-                    const u32 hs = d.rq_hstart[so];
-                    r.twt = (u16)clamp16(d, (u32)r.twt + (hs - r.enq));
-                    r.ctt = (u16)clamp16(d, (u32)r.ctt + (c - hs + 1));
-                    rew = dadd(rew, r.hop > 1 ? dmul(d.pen_hop, (double)(r.hop - 1)) : 0.0);
-                    buffer_push(d, lane, buf_head, buf_len, n_off, r);
+#pragma unroll
+            for (int s = 0; s < DMAX; s++) {
+                const bool ne = rql[s] > 0;
+                bool failed = ne && ar[s] > lkA[s];
+                if (ne && ar[s] == lkA[s]) failed = frng.b_of(ir[s]) > lkB[s];  // 2^-27 tie on the first word
+                const bool arrived = ne && !failed && c >= rqa[s];
+                rew = failed ? dadd(rew, d.pen_fail) : rew;
+                n_fail += failed;
+                n_fin += failed;
+                if (failed || arrived) {
+                    if (arrived) {
+                        union {
+                            Rec r;
+                            uint4 v[2];
+                        } uu;
+                        uu.v[0] = S.rqrec[(s * 2 + 0) * NT + tid];
+                        uu.v[1] = S.rqrec[(s * 2 + 1) * NT + tid];
+                        Rec r = uu.r;
+                        const u32 hs = S.rqhs[s * NT + tid];
+                        r.twt = (u16)sat16((u32)r.twt + (hs - r.enq), ovf);
+                        r.ctt = (u16)sat16((u32)r.ctt + (c - hs + 1), ovf);
+                        rew = dadd(rew, r.hop > 1 ? dmul(d.pen_hop, (double)(r.hop - 1)) : 0.0);
+                        buf.push(d, lane, n_off, r);  // buffer_queue.append, :333
+                    }
+                    // popleft, then promote the next record to head for call c+1
+                    u32 qh = S.rqhead[s * NT + tid];
+                    qh = qh + 1 == (u32)d.capR ? 0u : qh + 1;
+                    const u32 ql = rql[s] - 1;
+                    u32 arr = NEVER;
+                    if (ql > 0) {  // deeper than one: the next record lives in the global ring
+                        const uint4* q = reinterpret_cast<const uint4*>(d.rq + ((size_t)s * d.capR + qh) * P + lane);
+                        union {
+                            Rec r;
+                            uint4 v[2];
+                        } nx;
+                        nx.v[0] = q[0];
+                        nx.v[1] = q[1];
+                        S.rqrec[(s * 2 + 0) * NT + tid] = nx.v[0];
+                        S.rqrec[(s * 2 + 1) * NT + tid] = nx.v[1];
+                        S.rqhs[s * NT + tid] = c + 1;
+                        arr = arrive_at(c + 1, nx.r.ntx, nx.r.ctt);
+                    }
+                    S.rqdirty[s * NT + tid] = 0;
+                    S.rqhead[s * NT + tid] = qh;
+                    rql[s] = ql;
+                    rqa[s] = arr;
                 }
-                // popleft, then promote the next record to head for call c+1
-                qh = qh + 1 == (u32)d.capR ? 0u : qh + 1;
-                ql--;
-                d.rq_head[so] = qh;
-                u32 arr = NEVER;
-                if (ql > 0) {
-                    const Rec nx = load_rec(d.rq + ((size_t)s * d.capR + qh) * P + lane);
-                    d.rq_hstart[so] = c + 1;
-                    if (nx.ntx != T16_NEVER) arr = c + 1 + (nx.ntx > (u32)nx.ctt + 1 ? nx.ntx - nx.ctt - 1 : 0u);
-                }
-                s_rqlen[s * NT + tid] = ql;
-                s_rqarr[s * NT + tid] = arr;
             }
         }
     }
 
     // ---------------------------------------------------------------- phase C: per-env statistics, edge_computing_env.py:108-123
     if (L.valid) {
-        s_rew[tid] = rew;
-        s_ct[tid] = ct;
-        s_cnt[0 * NT + tid] = n_fin;
-        s_cnt[1 * NT + tid] = n_succ;
-        s_cnt[2 * NT + tid] = n_drop;
-        s_cnt[3 * NT + tid] = n_fail;
+        S.rew[tid] = rew;
+        S.ct[tid] = ct;
+        S.cnt[0 * NT + tid] = n_fin;
+        S.cnt[1 * NT + tid] = n_succ;
+        S.cnt[2 * NT + tid] = n_drop;
+        S.cnt[3 * NT + tid] = n_fail;
     }
     __syncthreads();
-    u32 step_now = 0;
     if (L.valid && node == 0) {
         double r = 0.0, t = 0.0;
         u32 c4[4] = {0, 0, 0, 0};
         for (int i = 0; i < N; i++) {  // node order, as the reference sums
-            r = dadd(r, s_rew[tid + i]);
-            t = dadd(t, s_ct[tid + i]);
-            for (int q = 0; q < 4; q++) c4[q] += s_cnt[q * NT + tid + i];
+            r = dadd(r, S.rew[tid + i]);
+            t = dadd(t, S.ct[tid + i]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) c4[q] += S.cnt[q * NT + tid + i];
         }
-        step_now = d.cur_step[L.env] + 1;  // :125
+        const u32 step_now = d.cur_step[L.env] + 1;  // :125
         d.cur_step[L.env] = step_now;
         d.tick[L.env] = c0 + (u32)d.S;
         if (reward) reward[L.env] = (float)r;
         if (completion_time) completion_time[L.env] = (float)t;
-        if (counters) {
-            int4 v = make_int4((int)c4[0], (int)c4[1], (int)c4[2], (int)c4[3]);
-            *reinterpret_cast<int4*>(counters + 4 * L.env) = v;
-        }
+        if (counters) *reinterpret_cast<int4*>(counters + 4 * L.env) = make_int4((int)c4[0], (int)c4[1], (int)c4[2], (int)c4[3]);
         if (terminated) terminated[L.env] = step_now >= (u32)d.T ? 1 : 0;  // :139-142
     }
 
-    // ---------------------------------------------------------------- phase D: generate_task, :127-128
+    // ---------------------------------------------------------------- phase D: generate_task (:127-128) + write-back
+    double wait_sum = 0.0;
     if (L.valid) {
-        generate_task(d, lane, node, trng, buf_head, buf_len, n_off, has_new, newt);
-        // write the working set back
+        generate_task(d, lane, bin_qn, bin_px2, bin_flip, trng, buf, n_off, has_new, newt);
         d.has_new[lane] = has_new;
         if (has_new) store_rec(d.newt + lane, newt);
         d.n_off[lane] = n_off;
-        d.buf_head[lane] = buf_head;
-        d.buf_len[lane] = buf_len;
-        d.wq_head[lane] = wq_head;
+        d.buf_head[lane] = buf.head;
+        d.buf_len[lane] = buf.len;
         d.wq_len[lane] = wq_len;
-        d.wq_min[lane] = wq_min;
+        for (u32 j = 0; j < wq_len; j++) {
+            const u32 pos = (wq_h + j) & wmask;
+            const double et = S.wqe[pos * NT + tid];
+            wait_sum = dadd(wait_sum, et);  // get_waiting_time, edge_node.py:99-104
+            if (wq_dirty) {
+                d.wqm[(size_t)j * P + lane] = S.wqm[pos * NT + tid];
+                d.wqe[(size_t)j * P + lane] = et;
+            }
+        }
         d.ex_n[lane] = ex_n;
-        for (u32 s = 0; s < ex_n; s++) {
-            d.exA[(size_t)s * P + lane] = s_exA[s * NT + tid];
-            d.exB[(size_t)s * P + lane] = s_exB[s * NT + tid];
+#pragma unroll
+        for (int s = 0; s < KMAX; s++) {
+            if ((u32)s < ex_n) {
+                d.exA[(size_t)s * P + lane] = (u64)exw[s] | ((u64)exh[s] << 32);
+                d.exB[(size_t)s * P + lane] = exT[s];
+                d.exC[(size_t)s * P + lane] = S.exC[s * NT + tid];
+            }
         }
-        for (int s = 0; s < deg; s++) {
-            d.rq_len[(size_t)s * P + lane] = s_rqlen[s * NT + tid];
-            d.rq_arrive[(size_t)s * P + lane] = s_rqarr[s * NT + tid];
+#pragma unroll
+        for (int s = 0; s < DMAX; s++) {
+            if (s < deg) {
+                const size_t so = (size_t)s * P + lane;
+                const u32 qh = S.rqhead[s * NT + tid];
+                d.rq_len[so] = rql[s];
+                d.rq_head[so] = qh;
+                d.rq_arrive[so] = rqa[s];
+                d.rq_hstart[so] = S.rqhs[s * NT + tid];
+                if (rql[s] > 0 && S.rqdirty[s * NT + tid]) {
+                    uint4* q = reinterpret_cast<uint4*>(d.rq + ((size_t)s * d.capR + qh) * P + lane);
+                    q[0] = S.rqrec[(s * 2 + 0) * NT + tid];
+                    q[1] = S.rqrec[(s * 2 + 1) * NT + tid];
+                }
+            }
         }
-        d.rng_pos[lane] = trng.pos;
-        d.rng_pos[P + lane] = frng.pos;
-        d.rng_cnt[lane] += trng.used;
-        d.rng_cnt[P + lane] += frng.used;
+        u32 pos, ahead, used;
+        trng.close(pos, ahead, used);
+        d.rng_pos[lane] = pos;
+        d.rng_ahead[lane] = ahead;
+        d.rng_cnt[lane] += 2ull * used;
+        frng.close(pos, ahead, used);
+        d.rng_pos[P + lane] = pos;
+        d.rng_ahead[P + lane] = ahead;
+        d.rng_cnt[P + lane] += 2ull * used;
+        if (ovf | lut.ovf) flag(d, EC_ST_TICK_OVERFLOW);
     }
 
     // ---------------------------------------------------------------- phase E: fused observation of the new state
+#ifdef ABL_NO_OBS
+    if (false) {
+#else
     if (next_obs || next_avail) {
-        __syncthreads();  // the sweep's compaction stores are ordered before the waiting-time loads
-        observe_block(d, L, wq_head, wq_len, has_new, newt, next_obs, next_avail, s_wql, s_hasnew, s_any, s_obs);
+#endif
+        __syncthreads();  // the failure-stream window is dead: reuse it as observation scratch
+        u32* s_full = S.fa;
+        u32* s_hasnew = s_full + NT;
+        u32* s_any = s_hasnew + NT;
+        float* s_obs = reinterpret_cast<float*>(s_any + NT);
+        observe_block(d, L, wq_len, wait_sum, has_new, newt, next_obs, next_avail, s_full, s_hasnew, s_any, s_obs);
     }
+}
+
+typedef void (*step_fn)(EcDev, const int64_t*, float*, uint8_t*, int32_t*, float*, float*, int32_t*);
+template <int KMAX>
+step_fn pick_step_d(int D) {
+    if (D <= 4) return k_step<KMAX, 4>;
+    if (D <= 8) return k_step<KMAX, 8>;
+    return nullptr;
+}
+step_fn pick_step(int k, int D, int* kmax, int* dmax) {
+    *dmax = D <= 4 ? 4 : 8;
+    if (k <= 4) return *kmax = 4, pick_step_d<4>(D);
+    if (k <= 8) return *kmax = 8, pick_step_d<8>(D);
+    if (k <= 12) return *kmax = 12, pick_step_d<12>(D);
+    return nullptr;
 }
 
 __global__ void k_copy_i32(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int64_t n) {
@@ -859,17 +1332,16 @@ __global__ void k_dump(EcDev d, int64_t env, double* rows, int64_t max_rows, int
             put(i, 1, j, t.size, t.cycles, t.hop, 0, 0, t.twt, t.ctt, (u32)(t.bwt + (int32_t)n_off));
             pos = pos + 1 == (u32)d.capB ? 0u : pos + 1;
         }
-        pos = d.wq_head[lane];
         for (u32 j = 0; j < d.wq_len[lane]; j++) {
-            const WRec w = d.wq[(size_t)pos * d.P + lane];
-            // size/cycles are not kept once a task is queued for execution: report et and 0
-            put(i, 2, j, w.et, 0.0, w.hop, now - w.enq, 0, w.twt, w.ctt, w.bwt);
-            pos = pos + 1 == (u32)d.capW ? 0u : pos + 1;
+            const WMeta w = wmeta_unpack(d.wqm[(size_t)j * d.P + lane]);
+            // size/cycles are not kept once a task is queued for execution: report execute_time and 0
+            put(i, 2, j, d.wqe[(size_t)j * d.P + lane], 0.0, w.hop, now - w.enq, 0, w.twt, w.ctt, w.bwt);
         }
         for (u32 j = 0; j < d.ex_n[lane]; j++) {
-            const u64 a = d.exA[(size_t)j * d.P + lane], b = d.exB[(size_t)j * d.P + lane];
-            put(i, 3, j, (double)f16(a, 2), (double)f16(a, 1), f16(a, 3), f16(b, 0), f16(a, 0), f16(b, 1), f16(b, 2),
-                f16(b, 3));
+            const u64 a = d.exA[(size_t)j * d.P + lane], b = d.exC[(size_t)j * d.P + lane];
+            // cols 3,4: the precomputed finish tick and the task_time at that tick
+            put(i, 3, j, (double)f16(a, 1), d.exB[(size_t)j * d.P + lane], f16(a, 2), f16(b, 0), f16(a, 0), f16(b, 1),
+                f16(b, 2), f16(b, 3));
         }
         for (int s = 0; s < d.deg[i]; s++) {
             const size_t so = (size_t)s * d.P + lane;
@@ -903,6 +1375,8 @@ struct ec_env {
     int envs_per_block;
     int64_t blocks;
     size_t lds_step, lds_obs;
+    step_fn step;
+    int kmax, dmax;
     std::vector<void*> allocs;
     size_t state_bytes;
 };
@@ -913,6 +1387,13 @@ int next_pow2(int v) {
     int p = 1;
     while (p < v) p <<= 1;
     return p;
+}
+
+FastDiv make_div(int dvs) {
+    FastDiv f;
+    f.d = (u32)dvs;
+    f.m = dvs == 1 ? 0u : (u32)(((1ull << 32) + (u64)dvs - 1) / (u64)dvs);
+    return f;
 }
 
 template <typename T>
@@ -949,6 +1430,13 @@ void free_all(ec_env* h) {
         if (rc_) return rc_;  \
     } while (0)
 
+// `random() > thr` as an integer test on the 53-bit numerator: M = floor(thr * 2^53)
+u64 threshold_m(double thr) {
+    if (!(thr > 0.0)) return 0;
+    if (thr >= 1.0) return 1ull << 53;
+    return (u64)floor(ldexp(thr, 53));
+}
+
 int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, int64_t env_id_base) {
     EcDev& d = h->d;
     const int N = cfg->n_nodes;
@@ -961,7 +1449,9 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     d.B = B;
     d.P = B * N;
     d.dt = cfg->mini_time_slot;
+    d.inv_dt = 1.0 / cfg->mini_time_slot;
     d.deadline = cfg->deadline;
+    d.dl_ticks = (int)(cfg->deadline / cfg->mini_time_slot);
     d.size_lo = cfg->task_size_min;
     d.size_range = cfg->task_size_max - cfg->task_size_min;  // numpy uniform: range = high - low
     d.cx_lo = cfg->task_complexity_min;
@@ -970,8 +1460,10 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     d.pen_fail = cfg->task_failure_penalty;
     d.rew_succ = cfg->task_success_reward;
     d.pen_hop = cfg->task_hop_penalty;
-    d.obs_size_norm = cfg->task_size_max * 1024 * 8;                                  // edge_node.py:126
-    d.obs_cyc_norm = cfg->task_complexity_max * cfg->task_size_max * 1024 * 8;       // edge_node.py:128
+    d.obs_size_norm = cfg->task_size_max * 1024 * 8;                             // edge_node.py:126
+    d.obs_cyc_norm = cfg->task_complexity_max * cfg->task_size_max * 1024 * 8;  // edge_node.py:128
+    d.divN = make_div(N);
+    d.divA = make_div(N + 1);
 
     // in-neighbour lists (ascending source id == the order receive_task visits its queues)
     std::vector<int> deg(N, 0);
@@ -983,7 +1475,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     }
     d.D = D;
     std::vector<int> in_src((size_t)N * D, -1), slot_of((size_t)N * N, -1);
-    std::vector<double> thr_link((size_t)N * D, 1.0);
+    std::vector<u64> thr_link_m((size_t)N * D, 1ull << 53);
     for (int i = 0; i < N; i++) {
         int c = 0;
         for (int s = 0; s < N; s++) {
@@ -992,14 +1484,14 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
             in_src[i * D + c] = s;
             slot_of[s * N + i] = c;
             // edge_node.py:321: exp(-transmission_failure_rate * mini_time_slot), rate taken from the sender's table
-            thr_link[i * D + c] = exp(-topo->tfr[s * N + i] * cfg->mini_time_slot);
+            thr_link_m[i * D + c] = threshold_m(exp(-topo->tfr[s * N + i] * cfg->mini_time_slot));
             c++;
         }
     }
 
     // ring capacities: bounds that hold for any policy within one episode
     const int steps_per_deadline = (int)ceil(cfg->deadline / (cfg->mini_time_slot * cfg->mini_slots));
-    d.capW = cfg->cap_wait > 0 ? cfg->cap_wait : next_pow2(steps_per_deadline + 3);
+    d.capW = next_pow2(cfg->cap_wait > 0 ? cfg->cap_wait : steps_per_deadline + 3);
     d.capR = cfg->cap_recv > 0 ? cfg->cap_recv : next_pow2(cfg->episode_limit + 2);
     d.capB = cfg->cap_buffer > 0 ? cfg->cap_buffer : next_pow2((D + 1) * (cfg->episode_limit + 2));
     d.maxTicks = cfg->max_ticks > 0 ? cfg->max_ticks : cfg->mini_slots * (cfg->episode_limit + 2);
@@ -1010,12 +1502,13 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     acc[0] = 0.0;
     for (int n = 1; n <= d.maxTicks; n++) acc[n] = acc[n - 1] + cfg->mini_time_slot;  // edge_node.py:216,250,254,316,319
 
-    std::vector<double> cap(N), thr_exec(N), qlen(N), qthr(N), bqn(N), bpx2(N), rate((size_t)N * N);
+    std::vector<double> cap(N), qlen(N), qthr(N), bqn(N), bpx2(N), rate((size_t)N * N);
+    std::vector<u64> thr_exec_m(N), adj_bits(N, 0);
     std::vector<float> obs_const((size_t)N * 3);
     std::vector<uint8_t> bflip(N), adj((size_t)N * (N + 1));
     for (int i = 0; i < N; i++) {
         cap[i] = topo->cpu_capacity[i];
-        thr_exec[i] = exp(-topo->efr[i] * cfg->mini_time_slot);  // edge_node.py:257
+        thr_exec_m[i] = threshold_m(exp(-topo->efr[i] * cfg->mini_time_slot));  // edge_node.py:257
         qlen[i] = topo->queue_len[i];
         qthr[i] = topo->queue_len[i] * cfg->rl_queue_coeff;
         obs_const[3 * i + 0] = (float)(topo->efr[i] / cfg->execution_failure_rate_max);
@@ -1030,13 +1523,16 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
         const double qn = exp(1 * log(q));
         bqn[i] = qn;
         bpx2[i] = ((1 - 1 + 1) * p * qn) / (1 * q);
+        if (N <= 64)
+            for (int j = 0; j < N; j++)
+                if (topo->adj[i * (N + 1) + j]) adj_bits[i] |= 1ull << j;
     }
     memcpy(rate.data(), topo->rate, sizeof(double) * N * N);
     memcpy(adj.data(), topo->adj, (size_t)N * (N + 1));
 
     EC_TRY(dev_upload(h, &d.acc, acc));
     EC_TRY(dev_upload(h, &d.cap, cap));
-    EC_TRY(dev_upload(h, &d.thr_exec, thr_exec));
+    EC_TRY(dev_upload(h, &d.thr_exec_m, thr_exec_m));
     EC_TRY(dev_upload(h, &d.qlen, qlen));
     EC_TRY(dev_upload(h, &d.qthr, qthr));
     EC_TRY(dev_upload(h, &d.obs_const, obs_const));
@@ -1045,27 +1541,30 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     EC_TRY(dev_upload(h, &d.bin_flip, bflip));
     EC_TRY(dev_upload(h, &d.deg, deg));
     EC_TRY(dev_upload(h, &d.in_src, in_src));
-    EC_TRY(dev_upload(h, &d.thr_link, thr_link));
+    EC_TRY(dev_upload(h, &d.thr_link_m, thr_link_m));
     EC_TRY(dev_upload(h, &d.slot_of, slot_of));
     EC_TRY(dev_upload(h, &d.rate, rate));
     EC_TRY(dev_upload(h, &d.adj, adj));
+    d.adj_bits = nullptr;
+    if (N <= 64) EC_TRY(dev_upload(h, &d.adj_bits, adj_bits));
 
     const size_t P = (size_t)d.P;
     EC_TRY(dev_alloc(h, &d.mt, 2 * P * MT_N));
     EC_TRY(dev_alloc(h, &d.rng_pos, 2 * P));
+    EC_TRY(dev_alloc(h, &d.rng_ahead, 2 * P));
     EC_TRY(dev_alloc(h, &d.rng_cnt, 2 * P));
     EC_TRY(dev_alloc(h, &d.has_new, P));
     EC_TRY(dev_alloc(h, &d.newt, P, true));
     EC_TRY(dev_alloc(h, &d.buf_head, P));
     EC_TRY(dev_alloc(h, &d.buf_len, P));
     EC_TRY(dev_alloc(h, &d.buf, (size_t)d.capB * P));
-    EC_TRY(dev_alloc(h, &d.wq_head, P));
     EC_TRY(dev_alloc(h, &d.wq_len, P));
-    EC_TRY(dev_alloc(h, &d.wq_min, P));
-    EC_TRY(dev_alloc(h, &d.wq, (size_t)d.capW * P));
+    EC_TRY(dev_alloc(h, &d.wqm, (size_t)d.capW * P));
+    EC_TRY(dev_alloc(h, &d.wqe, (size_t)d.capW * P));
     EC_TRY(dev_alloc(h, &d.ex_n, P));
     EC_TRY(dev_alloc(h, &d.exA, (size_t)d.k * P));
     EC_TRY(dev_alloc(h, &d.exB, (size_t)d.k * P));
+    EC_TRY(dev_alloc(h, &d.exC, (size_t)d.k * P));
     EC_TRY(dev_alloc(h, &d.rq_head, (size_t)D * P));
     EC_TRY(dev_alloc(h, &d.rq_len, (size_t)D * P));
     EC_TRY(dev_alloc(h, &d.rq_arrive, (size_t)D * P));
@@ -1077,19 +1576,46 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     EC_TRY(dev_alloc(h, &d.hop_hist, (size_t)B * d.H));
     EC_TRY(dev_alloc(h, &d.status, 1, true));
 
-    // launch geometry: whole envs per block; small batches use one wave per block to spread over the CUs
-    int threads = 256;
+    // launch geometry: whole envs per block (one wave for N <= 64).  The step is bound by the dependent chain
+    // of one wave, not by bandwidth, so a launch whose blocks are not all co-resident costs a second full round:
+    // pick the fewest environments per block (less divergence per wave) that still fits the chip in one round,
+    // and the densest packing once the batch is too large for that.
+    int threads = ((N + 63) / 64) * 64;
     if (const char* e = getenv("MARL_AMD_EC_THREADS")) threads = atoi(e);
-    else if (d.P <= 256 * 256) threads = 64;
-    if (threads < N) threads = ((N + 63) / 64) * 64;
-    if (threads > 1024 || threads % 64 != 0) return ec::fail(EC_EINVAL, "threads per block %d unsupported (n_nodes=%d)", threads, N);
+    if (threads < N || threads > 256 || threads % 64 != 0)
+        return ec::fail(EC_EINVAL, "threads per block %d unsupported (n_nodes=%d)", threads, N);
+    h->step = pick_step(d.k, D, &h->kmax, &h->dmax);
+    if (!h->step) return ec::fail(EC_EINVAL, "k=%d / max in-degree %d exceed the compiled limits (12 / 8)", d.k, D);
+    const int epb_max = threads / N;
+    int epb = epb_max;
+    if (const char* e = getenv("MARL_AMD_EC_EPB")) {
+        epb = atoi(e);
+    } else {
+        hipDeviceProp_t prop;
+        EC_HIP(hipGetDeviceProperties(&prop, h->device));
+        for (int cand = 1; cand <= epb_max; cand++) {
+            const size_t lds = step_lds_bytes(cand * N, h->kmax, h->dmax, d.capW);
+            if (lds > 160 * 1024) break;
+            EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->step),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            int per_cu = 0;
+            EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(h->step), threads, lds));
+            const int64_t resident = (int64_t)per_cu * prop.multiProcessorCount;
+            if ((B + cand - 1) / cand <= resident) {
+                epb = cand;
+                break;
+            }
+        }
+    }
+    if (epb < 1 || epb * N > threads) return ec::fail(EC_EINVAL, "envs per block %d does not fit %d threads", epb, threads);
+    d.epb = epb;
     h->threads = threads;
-    h->envs_per_block = threads / N;
-    h->blocks = (B + h->envs_per_block - 1) / h->envs_per_block;
-    h->lds_obs = (size_t)threads * (3 * 4 + 9 * 4);
-    h->lds_step = (size_t)threads * ((size_t)d.k * 16 + 16 + (size_t)D * 8 + 16 + 12 + 36);
+    h->envs_per_block = epb;
+    h->blocks = (B + epb - 1) / epb;
+    h->lds_obs = (size_t)epb * N * (3 * 4 + 9 * 4);
+    h->lds_step = step_lds_bytes(epb * N, h->kmax, h->dmax, d.capW);
     if (h->lds_step > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_step);
-    EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_step), hipFuncAttributeMaxDynamicSharedMemorySize,
+    EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->step), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)h->lds_step));
 
     const u32 ts = (u32)(cfg->task_seed + env_id_base), fs = (u32)(cfg->failure_seed + env_id_base);
@@ -1108,9 +1634,9 @@ extern "C" {
 int ec_create(const ec_config* cfg, const ec_topology* topo, int64_t n_envs, int64_t env_id_base, int device,
               ec_handle* out) {
     if (!cfg || !topo || !out) return ec::fail(EC_EINVAL, "null argument");
-    if (cfg->n_nodes < 2 || cfg->n_nodes > 1024) return ec::fail(EC_EINVAL, "n_nodes %d out of range [2,1024]", cfg->n_nodes);
+    if (cfg->n_nodes < 2 || cfg->n_nodes > 256) return ec::fail(EC_EINVAL, "n_nodes %d out of range [2,256]", cfg->n_nodes);
     if (n_envs < 1) return ec::fail(EC_EINVAL, "n_envs must be positive");
-    if (cfg->k < 1 || cfg->k > 64) return ec::fail(EC_EINVAL, "k %d out of range [1,64]", cfg->k);
+    if (cfg->k < 1 || cfg->k > 12) return ec::fail(EC_EINVAL, "k %d out of range [1,12]", cfg->k);
     if (cfg->mini_slots < 1 || cfg->mini_time_slot <= 0) return ec::fail(EC_EINVAL, "bad mini slot configuration");
     const int64_t top = n_envs + env_id_base + cfg->n_nodes;
     // numpy: RandomState(seed) needs 0 <= seed < 2**32
@@ -1161,7 +1687,7 @@ int ec_observe(ec_handle h, float* obs, int32_t* avail, void* stream) {
 int ec_step(ec_handle h, const int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
             float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail, void* stream) {
     if (!h || !actions) return ec::fail(EC_EINVAL, "null handle or actions");
-    hipLaunchKernelGGL(k_step, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_step, (hipStream_t)stream, h->d,
+    hipLaunchKernelGGL(h->step, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_step, (hipStream_t)stream, h->d,
                        actions, reward, terminated, counters, completion_time, next_obs, next_avail);
     if (hop_hist) {
         const int64_t n = h->d.B * h->d.H;
@@ -1239,14 +1765,14 @@ int ec_debug_live_tasks(ec_handle h, int64_t* total_host) {
 
 int ec_info(ec_handle h, int64_t* info_host, int32_t n) {
     if (!h || !info_host) return ec::fail(EC_EINVAL, "null argument");
-    const int64_t v[12] = {h->d.B, h->d.N, h->d.k, h->d.D, h->d.capB, h->d.capR, h->d.capW, h->d.maxTicks,
+    const int64_t v[13] = {h->d.B, h->d.N, h->d.k, h->d.D, h->d.capB, h->d.capR, h->d.capW, h->d.maxTicks,
                            h->threads, h->envs_per_block, (int64_t)(h->state_bytes & 0xffffffffull),
-                           (int64_t)(h->state_bytes >> 32)};
-    for (int i = 0; i < n && i < 12; i++) info_host[i] = v[i];
+                           (int64_t)(h->state_bytes >> 32), (int64_t)h->lds_step};
+    for (int i = 0; i < n && i < 13; i++) info_host[i] = v[i];
     return EC_OK;
 }
 
 const char* ec_last_error(void) { return ec::err_buf(); }
-const char* ec_version(void) { return "marl_amd 0.1 (gfx950)"; }
+const char* ec_version(void) { return "marl_amd 0.4 (gfx950)"; }
 
 }  // extern "C"
