@@ -1,0 +1,40 @@
+"""On-policy rollout storage with the reference's EpisodeBuffer interface (buffer/episode_buffer.py:4-46),
+kept resident in HBM: `insert` is a device-to-device copy of one time slice and `sample` returns the
+tensors themselves, so the ~540 MB/iteration host-to-device copy of the reference disappears."""
+import torch as th
+
+
+class EpisodeBuffer:
+    def __init__(self, args, device=None):
+        self.args = args
+        self.device = th.device(device if device is not None else ("cuda" if th.cuda.is_available() else "cpu"))
+        B, T, N = args.n_threads, args.episode_limit, args.n_agents
+        kw = dict(device=self.device)
+        self.obs = th.zeros(B, T, N, args.obs_shape, dtype=th.float, **kw)
+        self.avail_actions = th.zeros(B, T, N, args.n_actions, dtype=th.int, **kw)
+        self.actions = th.zeros(B, T, N, 1, dtype=th.long, **kw)
+        self.rewards = th.zeros(B, T, N, 1, dtype=th.float, **kw)
+        self.masks = th.zeros(B, T, N, 1, dtype=th.float, **kw)
+        self.next_obs = th.zeros(B, T, N, args.obs_shape, dtype=th.float, **kw)
+        self.t = 0
+
+    def insert(self, obs, avail_actions, actions, rewards, masks, next_obs):
+        t = self.t
+        self.obs[:, t].copy_(obs, non_blocking=True)
+        self.avail_actions[:, t].copy_(avail_actions, non_blocking=True)
+        self.actions[:, t].copy_(actions, non_blocking=True)
+        self.rewards[:, t].copy_(rewards, non_blocking=True)
+        self.masks[:, t].copy_(masks, non_blocking=True)
+        self.next_obs[:, t].copy_(next_obs, non_blocking=True)
+        self.t += 1
+
+    def sample(self):
+        return self.obs, self.avail_actions, self.actions, self.rewards, self.masks, self.next_obs
+
+    def reset(self):
+        for t in (self.obs, self.avail_actions, self.actions, self.rewards, self.masks, self.next_obs):
+            t.zero_()
+        self.t = 0
+
+    def can_sample(self) -> bool:
+        return self.t >= self.args.episode_limit

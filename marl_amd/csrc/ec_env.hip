@@ -38,10 +38,15 @@ typedef uint16_t u16;
 
 constexpr int MT_N = 624;
 constexpr int MT_M = 397;
+constexpr int MT_MIRROR = 96;              // words [0, MT_MIRROR) are repeated after the state (wrap-free reads)
+constexpr int MT_STRIDE = MT_N + MT_MIRROR; // words per stream in memory
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(8)));
 constexpr u32 NEVER = 0xFFFFFFFFu;
 constexpr u32 T16_NEVER = 0xFFFFu;
-constexpr int RB_FAIL = 48;  // draws of the failure stream held in the LDS window (>= KMAX + DMAX)
+constexpr int RB_FAIL = 48;  // draws of the failure stream held in the LDS window (>= KMAX + DMAX; 2*RB_FAIL <= MT_MIRROR)
+constexpr int AHEAD_FAIL = 2 * RB_FAIL;  // words regenerated ahead of the failure cursor at kernel entry
 constexpr int RB_TASK = 4;   // doubles of the task stream staged per refill (binomial + id + size + cycles)
+constexpr int AHEAD_TASK = 2 * RB_TASK;
 constexpr int ACC_LDS = 256; // low part of the tick LUT kept in LDS
 
 // task record while in buffer_queue / new_task / a receiving queue (32 B)
@@ -121,7 +126,7 @@ struct EcDev {
     const uint8_t* adj;       // [N][A]
     const u64* adj_bits;      // [N] adj rows as bit masks (N <= 64), else null
     // per-lane state
-    u32* mt;        // [2][P][624]
+    u32* mt;        // [2][P][MT_STRIDE]
     u32* rng_pos;   // [2][P] next word to consume
     u32* rng_ahead; // [2][P] words already regenerated beyond rng_pos
     u64* rng_cnt;   // [2][P] words consumed so far
@@ -148,6 +153,7 @@ struct EcDev {
     u32* tick;      // [B] execute/receive call index
     int32_t* hop_hist;  // [B][H]
     u32* status;    // [1]
+    u64* stamps;    // [blocks][16] phase time stamps (EC_STAMPS diagnostic build only), else null
 };
 
 // ------------------------------------------------------------------------------------------ helpers
@@ -159,14 +165,15 @@ __device__ __forceinline__ void flag(const EcDev& d, u32 bit) { atomicOr(d.statu
 
 // tick LUT: low entries from LDS (when s_acc != nullptr), the rest from global.  An index beyond the LUT is
 // clamped and remembered in `ovf` (reported through the status word by the caller).
+typedef const double __attribute__((address_space(3))) * lds_cdouble_ptr;
 struct Lut {
     const EcDev& d;
-    const double* s_acc;
+    lds_cdouble_ptr s_acc;  // explicitly LDS: keeps the two loads below from being merged into one flat load
     mutable u32 ovf;
     __device__ __forceinline__ double at(u32 n) const {
         ovf |= n > (u32)d.maxTicks ? 1u : 0u;
         n = n > (u32)d.maxTicks ? (u32)d.maxTicks : n;
-        if (s_acc && n < (u32)ACC_LDS) return s_acc[n];
+        if (n < (u32)ACC_LDS) return s_acc[n];
         return d.acc[n];
     }
     // smallest n with acc[n] >= x, T16_NEVER if none in the LUT
@@ -244,12 +251,21 @@ __device__ __forceinline__ double mt_to_double(u32 w0, u32 w1) {
 }
 
 // MT19937 stream of one lane (numpy RandomState / mt19937_gen).  Positions are regenerated in place and in
-// order, possibly `ahead` words beyond the consumption cursor `pos`: a word at position q needs the
-// not-yet-regenerated word q+1 and the current word (q+397) mod 624, which in-order regeneration provides
-// for any batch shorter than 227 words.  Only 53-bit doubles (two words) are drawn, so pos stays even.
+// order, `ahead` words beyond the consumption cursor `pos`: a word at position q needs the not-yet-regenerated
+// word q+1 and the current word (q+397) mod 624, which in-order regeneration provides for any batch shorter
+// than 227 words.  Only 53-bit doubles (two words) are drawn, so pos stays even.
 //
-// One pair: returns the (regenerated) words at positions q, q+1.  `fresh`: the pair was regenerated by an
-// earlier batch and only needs to be read.
+// Memory form: MT_STRIDE words per stream = the 624 state words + a mirror of the first MT_MIRROR words, so that
+// a window of already regenerated words can be read with wide loads without wrapping.  The step kernel keeps
+// `ahead` >= a whole window at kernel entry: regeneration happens at the END of a step, 64 words at a time, by
+// the whole wave for one stream (coalesced), and the entry path only reads and tempers.
+__device__ __forceinline__ void mt_store_pair(u32* mt, u32 q, uint2 n) {
+    *reinterpret_cast<uint2*>(mt + q) = n;
+    if (q < (u32)MT_MIRROR) *reinterpret_cast<uint2*>(mt + q + MT_N) = n;
+}
+
+// One pair (per-lane slow path): returns the (regenerated) words at positions q, q+1.  `fresh`: the pair was
+// regenerated by an earlier batch and only needs to be read.
 struct MtPairIn {
     uint2 cur;
     u32 nxt, f0, f1;
@@ -268,8 +284,30 @@ __device__ __forceinline__ MtPairIn mt_pair_load(const u32* mt, u32 q, bool fres
 __device__ __forceinline__ uint2 mt_pair_finish(u32* mt, u32 q, bool fresh, const MtPairIn& in) {
     if (fresh) return in.cur;
     const uint2 n = make_uint2(mt_next(in.cur.x, in.cur.y, in.f0), mt_next(in.cur.y, in.nxt, in.f1));
-    *reinterpret_cast<uint2*>(mt + q) = n;
+    mt_store_pair(mt, q, n);
     return n;
+}
+
+// Wave-cooperative regeneration: while some lane of the wave has fewer than `want` words regenerated ahead of
+// its cursor, the 64 lanes regenerate the next 64 words of that lane's stream (one word each: three coalesced
+// loads, one coalesced store).  Must be called by all 64 lanes of the wave.  mt_of_lane: this lane's stream.
+__device__ __forceinline__ void mt_coop_refill(u32* __restrict__ mt_all, u64 stream_of_lane, u32 pos, u32& ahead,
+                                               u32 want, bool active) {
+    const u32 lid = __lane_id();
+    unsigned long long need = __ballot(active && ahead < want);
+    while (need) {
+        const int o = __ffsll((long long)need) - 1;
+        const u64 ostream = __shfl((unsigned long long)stream_of_lane, o);
+        const u32 opos = __shfl(pos, o), oahead = __shfl(ahead, o);
+        u32* omt = mt_all + ostream * MT_STRIDE;
+        const u32 q = mt_wrap(mt_wrap(opos + oahead) + lid);
+        const u32 cur = omt[q], nxt = omt[mt_wrap(q + 1)], far = omt[mt_wrap(q + MT_M)];
+        const u32 n = mt_next(cur, nxt, far);
+        omt[q] = n;
+        if (q < (u32)MT_MIRROR) omt[q + MT_N] = n;
+        if ((int)lid == o) ahead += 64;
+        need = __ballot(active && ahead < want);
+    }
 }
 
 // Failure stream (edge_node.py:258,322): the tests are `random() > threshold` with random() =
@@ -286,7 +324,27 @@ struct RngFail {
     u32* buf;
     int stride;
 
-    // stage draws [0, n) of the window (n <= capacity); regenerates whatever is not yet regenerated
+    // entry path: the window's words are already regenerated (ahead >= 2n): wide reads + temper only
+    __device__ __forceinline__ void stage_fresh(u32 n) {
+        const u32* w = mt + pos;  // no wrap thanks to the mirror
+        for (u32 i0 = 0; i0 < n; i0 += 8) {
+            u32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (i0 + 2 * j < n) v[j] = *reinterpret_cast<const u32x4*>(w + 2 * (i0 + 2 * j));
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 i = i0 + 2 * j;
+                if (i < n) {
+                    buf[i * stride] = mt_temper(v[j].x) >> 5;
+                    buf[(i + 1) * stride] = mt_temper(v[j].z) >> 5;  // slot i+1 < RB_FAIL + 1 (window has a spare slot)
+                }
+            }
+        }
+        staged = n;
+        idx = 0;
+    }
+    // slow path: stage draws [0, n), regenerating per lane whatever is not yet regenerated
     __device__ __forceinline__ void stage(u32 n) {
         for (u32 i0 = 0; i0 < n; i0 += 4) {
             MtPairIn in[4];
@@ -315,11 +373,12 @@ struct RngFail {
         buf = buf_;
         stride = stride_;
         used = 0;
-        stage(n);
+        if (ahead >= 2 * n) stage_fresh(n);
+        else stage(n);
     }
-    // slide the window so that it starts at the next unconsumed draw (rare: only when a lane's per-step bound
-    // exceeds the window capacity)
-    __device__ __noinline__ void restage(u32 n) {
+    // slide the window so that it starts at the next unconsumed draw (only when a lane's per-step bound exceeds
+    // the window capacity)
+    __device__ __forceinline__ void restage(u32 n) {
         pos = mt_wrap(pos + 2 * idx);
         ahead -= 2 * idx;
         used += idx;
@@ -340,16 +399,30 @@ struct RngTask {
     u32* mt;
     u32 pos, ahead;
     u32 idx, used;
-    double u[RB_TASK];
+    double u0, u1, u2, u3;
+    __device__ __forceinline__ void stage_fresh() {
+        static_assert(RB_TASK == 4, "two wide loads");
+        const u32x4 v0 = *reinterpret_cast<const u32x4*>(mt + pos);
+        const u32x4 v1 = *reinterpret_cast<const u32x4*>(mt + pos + 4);
+        u0 = mt_to_double(v0.x, v0.y);
+        u1 = mt_to_double(v0.z, v0.w);
+        u2 = mt_to_double(v1.x, v1.y);
+        u3 = mt_to_double(v1.z, v1.w);
+        idx = 0;
+    }
     __device__ __forceinline__ void stage() {
-        MtPairIn in[RB_TASK];
-#pragma unroll
-        for (int i = 0; i < RB_TASK; i++) in[i] = mt_pair_load(mt, mt_wrap(pos + 2 * i), 2u * i < ahead);
-#pragma unroll
-        for (int i = 0; i < RB_TASK; i++) {
-            const uint2 w = mt_pair_finish(mt, mt_wrap(pos + 2 * i), 2u * i < ahead, in[i]);
-            u[i] = mt_to_double(w.x, w.y);
-        }
+        MtPairIn i0 = mt_pair_load(mt, mt_wrap(pos + 0), 0u < ahead);
+        MtPairIn i1 = mt_pair_load(mt, mt_wrap(pos + 2), 2u < ahead);
+        MtPairIn i2 = mt_pair_load(mt, mt_wrap(pos + 4), 4u < ahead);
+        MtPairIn i3 = mt_pair_load(mt, mt_wrap(pos + 6), 6u < ahead);
+        const uint2 w0 = mt_pair_finish(mt, mt_wrap(pos + 0), 0u < ahead, i0);
+        const uint2 w1 = mt_pair_finish(mt, mt_wrap(pos + 2), 2u < ahead, i1);
+        const uint2 w2 = mt_pair_finish(mt, mt_wrap(pos + 4), 4u < ahead, i2);
+        const uint2 w3 = mt_pair_finish(mt, mt_wrap(pos + 6), 6u < ahead, i3);
+        u0 = mt_to_double(w0.x, w0.y);
+        u1 = mt_to_double(w1.x, w1.y);
+        u2 = mt_to_double(w2.x, w2.y);
+        u3 = mt_to_double(w3.x, w3.y);
         ahead = ahead > 2u * RB_TASK ? ahead : 2u * RB_TASK;
         idx = 0;
     }
@@ -358,7 +431,8 @@ struct RngTask {
         pos = pos_;
         ahead = ahead_;
         used = 0;
-        stage();
+        if (ahead >= 2u * RB_TASK) stage_fresh();
+        else stage();
     }
     __device__ __forceinline__ double next() {
         if (idx == (u32)RB_TASK) {  // only after a binomial redraw
@@ -367,9 +441,7 @@ struct RngTask {
             used += idx;
             stage();
         }
-        double r = u[0];
-#pragma unroll
-        for (int i = 1; i < RB_TASK; i++) r = idx == (u32)i ? u[i] : r;
+        const double r = idx == 0 ? u0 : idx == 1 ? u1 : idx == 2 ? u2 : u3;
         idx++;
         return r;
     }
@@ -502,9 +574,10 @@ __global__ void k_seed(EcDev d, u32 task_seed0, u32 fail_seed0) {
     const int node = (int)(lane - env * d.N);
     for (int s = 0; s < 2; s++) {
         u32 seed = (s == 0 ? task_seed0 : fail_seed0) + (u32)env + (u32)node;
-        u32* mt = d.mt + ((size_t)s * d.P + lane) * MT_N;
+        u32* mt = d.mt + ((size_t)s * d.P + lane) * MT_STRIDE;
         for (int i = 0; i < MT_N; i++) {
             mt[i] = seed;
+            if (i < MT_MIRROR) mt[i + MT_N] = seed;
             seed = 1812433253u * (seed ^ (seed >> 30)) + (u32)(i + 1);
         }
         d.rng_pos[(size_t)s * d.P + lane] = 0;
@@ -534,7 +607,7 @@ __global__ void k_initial_generate(EcDev d) {
     const int64_t lane = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= d.P) return;
     const int node = (int)(lane % d.N);
-    RngDirect trng{d.mt + (size_t)lane * MT_N, d.rng_pos[lane], 0};
+    RngDirect trng{d.mt + (size_t)lane * MT_STRIDE, d.rng_pos[lane], 0};
     Buffer buf;
     buf.head = d.buf_head[lane];
     buf.len = d.buf_len[lane];  // 0 at construction
@@ -547,6 +620,18 @@ __global__ void k_initial_generate(EcDev d) {
     d.buf_len[lane] = buf.len;
     d.has_new[lane] = hn;
     if (hn) store_rec(d.newt + lane, nt);
+}
+
+// establishes the step kernel's entry invariant: a whole window regenerated ahead of both cursors
+__global__ void k_prime_rng(EcDev d) {
+    const int64_t lane = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = lane < d.P;
+    const int64_t l = ok ? lane : 0;
+    for (int s = 0; s < 2; s++) {
+        u32 pos = d.rng_pos[(size_t)s * d.P + l], ahead = d.rng_ahead[(size_t)s * d.P + l];
+        mt_coop_refill(d.mt, (u64)s * d.P + l, pos, ahead, s == 0 ? AHEAD_TASK : AHEAD_FAIL, ok);
+        if (ok) d.rng_ahead[(size_t)s * d.P + l] = ahead;
+    }
 }
 
 // edge_computing_env.py:145-148 / edge_node.py:171-177
@@ -683,12 +768,24 @@ __host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int
     b += (size_t)NT * capW * (16 + 8);
     b += (size_t)NT * KMAX * 8;
     b += (size_t)NT * DMAX * (32 + 5 * 4);
-    b += (size_t)NT * RB_FAIL * 4;
+    b += (size_t)NT * (RB_FAIL + 1) * 4;
     b += (size_t)NT * (8 + 8 + 16);
     return b + 64;
 }
 
 constexpr u32 KIND_SUCCESS = 1u << 16;
+
+#ifdef EC_STAMPS
+#define EC_STAMP(i)                                                                           \
+    do {                                                                                      \
+        __syncthreads();                                                                      \
+        if (threadIdx.x == 0 && d.stamps) d.stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define EC_STAMP(i) \
+    do {            \
+    } while (0)
+#endif
 
 // EdgeComputingEnv.step (edge_computing_env.py:84-143) for the envs of this block.
 // KMAX >= k and DMAX >= max in-degree are compile-time so that the executing slots and the receiving-queue
@@ -717,7 +814,7 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         S.exC = reinterpret_cast<u64*>(p);       p += (size_t)NT * KMAX * 8;
         S.rew = reinterpret_cast<double*>(p);    p += (size_t)NT * 8;
         S.ct = reinterpret_cast<double*>(p);     p += (size_t)NT * 8;
-        S.fa = reinterpret_cast<u32*>(p);        p += (size_t)NT * RB_FAIL * 4;
+        S.fa = reinterpret_cast<u32*>(p);        p += (size_t)NT * (RB_FAIL + 1) * 4;
         S.rqhs = reinterpret_cast<u32*>(p);      p += (size_t)NT * DMAX * 4;
         S.rqhead = reinterpret_cast<u32*>(p);    p += (size_t)NT * DMAX * 4;
         S.rqdirty = reinterpret_cast<u32*>(p);   p += (size_t)NT * DMAX * 4;
@@ -725,7 +822,7 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         S.rqarr = reinterpret_cast<u32*>(p);     p += (size_t)NT * DMAX * 4;
         S.cnt = reinterpret_cast<u32*>(p);       p += (size_t)NT * 16;
     }
-    Lut lut{d, S.acc, 0u};
+    Lut lut{d, (lds_cdouble_ptr)S.acc, 0u};
 
     {  // block-shared low part of the tick LUT
         const int nacc = d.maxTicks + 1 < ACC_LDS ? d.maxTicks + 1 : ACC_LDS;
@@ -735,6 +832,7 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
     const LaneId L = lane_id(d);
     const int64_t lane = L.lane;
     const int node = L.node;
+    EC_STAMP(0);
 
     // ---------------------------------------------------------------- stage the lane's working set
     u32 c0 = 0, has_new = 0, n_off = 0, ex_n = 0, wq_h = 0, wq_len = 0, wq_min = NEVER, ovf = 0;
@@ -835,13 +933,14 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
             }
         }
 #ifdef ABL_NO_TRNG
-        trng.mt = d.mt + (size_t)lane * MT_N; trng.pos = tpos; trng.ahead = 8; trng.idx = 0; trng.used = 0;
-        for (int i = 0; i < RB_TASK; i++) trng.u[i] = 0.3 + 0.1 * i;
+        trng.mt = d.mt + (size_t)lane * MT_STRIDE; trng.pos = tpos; trng.ahead = 8; trng.idx = 0; trng.used = 0;
+        trng.u0 = 0.3; trng.u1 = 0.4; trng.u2 = 0.5; trng.u3 = 0.6;
 #else
-        trng.open(d.mt + (size_t)lane * MT_N, tpos, tahead);
+        trng.open(d.mt + (size_t)lane * MT_STRIDE, tpos, tahead);
 #endif
     }
     __syncthreads();
+    EC_STAMP(1);
 
     // ---------------------------------------------------------------- phase A: offload_task, edge_node.py:199-234
     if (L.valid && has_new && action != N) {
@@ -907,6 +1006,7 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         }
     }
     __syncthreads();  // pushes into the LDS queue heads are visible to their destination lanes
+    EC_STAMP(2);
 
     // ---------------------------------------------------------------- failure-stream window
     // Within a step no queue gains a task after phase A, so this bounds the lane's draws: per mini-slot at most
@@ -925,15 +1025,16 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         const u32 n_ex = ex_n + wq_len < (u32)d.k ? ex_n + wq_len : (u32)d.k;
         draw_bound = (u32)d.S * (n_ex + n_ne);
 #ifdef ABL_NO_FRNG
-        frng.open(d.mt + ((size_t)P + lane) * MT_N, d.rng_pos[P + lane], d.rng_ahead[P + lane], S.fa + tid, NT, 0);
+        frng.open(d.mt + ((size_t)P + lane) * MT_STRIDE, d.rng_pos[P + lane], d.rng_ahead[P + lane], S.fa + tid, NT, 0);
         frng.staged = RB_FAIL;
         draw_bound = 0;
 #else
-        frng.open(d.mt + ((size_t)P + lane) * MT_N, d.rng_pos[P + lane], d.rng_ahead[P + lane], S.fa + tid, NT,
+        frng.open(d.mt + ((size_t)P + lane) * MT_STRIDE, d.rng_pos[P + lane], d.rng_ahead[P + lane], S.fa + tid, NT,
                   draw_bound < (u32)RB_FAIL ? draw_bound : (u32)RB_FAIL);
 #endif
     }
 
+    EC_STAMP(3);
     // ---------------------------------------------------------------- phase B: mini-slots, edge_computing_env.py:101-105
     double rew = 0.0, ct = 0.0;
     u32 n_fail = 0, n_drop = 0, n_fin = 0, n_succ = 0;
@@ -1143,9 +1244,14 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
                     rqa[s] = arr;
                 }
             }
+#ifdef EC_STAMPS
+            if (ms == 0 && threadIdx.x == 0 && d.stamps) d.stamps[(size_t)blockIdx.x * 16 + 9] = wall_clock64();
+            if (ms == 1 && threadIdx.x == 0 && d.stamps) d.stamps[(size_t)blockIdx.x * 16 + 10] = wall_clock64();
+#endif
         }
     }
 
+    EC_STAMP(4);
     // ---------------------------------------------------------------- phase C: per-env statistics, edge_computing_env.py:108-123
     if (L.valid) {
         S.rew[tid] = rew;
@@ -1174,6 +1280,7 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         if (terminated) terminated[L.env] = step_now >= (u32)d.T ? 1 : 0;  // :139-142
     }
 
+    EC_STAMP(5);
     // ---------------------------------------------------------------- phase D: generate_task (:127-128) + write-back
     double wait_sum = 0.0;
     if (L.valid) {
@@ -1229,7 +1336,23 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         d.rng_cnt[P + lane] += 2ull * used;
         if (ovf | lut.ovf) flag(d, EC_ST_TICK_OVERFLOW);
     }
+    EC_STAMP(6);
+    {   // regenerate ahead for the next step (whole wave per stream, coalesced)
+        u32 tpos = 0, tah = 0, fpos = 0, fah = 0, dr;
+        if (L.valid) {
+            trng.close(tpos, tah, dr);
+            frng.close(fpos, fah, dr);
+        }
+        const u32 tah0 = tah, fah0 = fah;
+        mt_coop_refill(d.mt, (u64)(L.valid ? lane : 0), tpos, tah, AHEAD_TASK, L.valid);
+        mt_coop_refill(d.mt, (u64)P + (u64)(L.valid ? lane : 0), fpos, fah, AHEAD_FAIL, L.valid);
+        if (L.valid) {
+            if (tah != tah0) d.rng_ahead[lane] = tah;
+            if (fah != fah0) d.rng_ahead[P + lane] = fah;
+        }
+    }
 
+    EC_STAMP(7);
     // ---------------------------------------------------------------- phase E: fused observation of the new state
 #ifdef ABL_NO_OBS
     if (false) {
@@ -1243,6 +1366,7 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         float* s_obs = reinterpret_cast<float*>(s_any + NT);
         observe_block(d, L, wq_len, wait_sum, has_new, newt, next_obs, next_avail, s_full, s_hasnew, s_any, s_obs);
     }
+    EC_STAMP(8);
 }
 
 typedef void (*step_fn)(EcDev, const int64_t*, float*, uint8_t*, int32_t*, float*, float*, int32_t*);
@@ -1549,7 +1673,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     if (N <= 64) EC_TRY(dev_upload(h, &d.adj_bits, adj_bits));
 
     const size_t P = (size_t)d.P;
-    EC_TRY(dev_alloc(h, &d.mt, 2 * P * MT_N));
+    EC_TRY(dev_alloc(h, &d.mt, 2 * P * MT_STRIDE));
     EC_TRY(dev_alloc(h, &d.rng_pos, 2 * P));
     EC_TRY(dev_alloc(h, &d.rng_ahead, 2 * P));
     EC_TRY(dev_alloc(h, &d.rng_cnt, 2 * P));
@@ -1575,6 +1699,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     EC_TRY(dev_alloc(h, &d.tick, (size_t)B));
     EC_TRY(dev_alloc(h, &d.hop_hist, (size_t)B * d.H));
     EC_TRY(dev_alloc(h, &d.status, 1, true));
+    d.stamps = nullptr;
 
     // launch geometry: whole envs per block (one wave for N <= 64).  The step is bound by the dependent chain
     // of one wave, not by bandwidth, so a launch whose blocks are not all co-resident costs a second full round:
@@ -1617,11 +1742,15 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     if (h->lds_step > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_step);
     EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->step), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)h->lds_step));
+#ifdef EC_STAMPS
+    EC_TRY(dev_alloc(h, &d.stamps, (size_t)h->blocks * 16, true));
+#endif
 
     const u32 ts = (u32)(cfg->task_seed + env_id_base), fs = (u32)(cfg->failure_seed + env_id_base);
     const int64_t gb = (d.P + 255) / 256;
     hipLaunchKernelGGL(k_seed, dim3((unsigned)gb), dim3(256), 0, 0, d, ts, fs);
     hipLaunchKernelGGL(k_initial_generate, dim3((unsigned)gb), dim3(256), 0, 0, d);
+    hipLaunchKernelGGL(k_prime_rng, dim3((unsigned)gb), dim3(256), 0, 0, d);
     EC_HIP(hipGetLastError());
     EC_HIP(hipDeviceSynchronize());
     return EC_OK;
@@ -1771,6 +1900,16 @@ int ec_info(ec_handle h, int64_t* info_host, int32_t n) {
     for (int i = 0; i < n && i < 13; i++) info_host[i] = v[i];
     return EC_OK;
 }
+
+#ifdef EC_STAMPS
+/* diagnostic build only: copy the per-block phase stamps of the last ec_step to the host */
+int ec_debug_stamps(ec_handle h, uint64_t* out_host, int64_t* n_blocks) {
+    EC_HIP(hipDeviceSynchronize());
+    EC_HIP(hipMemcpy(out_host, h->d.stamps, sizeof(u64) * 16 * (size_t)h->blocks, hipMemcpyDeviceToHost));
+    *n_blocks = h->blocks;
+    return EC_OK;
+}
+#endif
 
 const char* ec_last_error(void) { return ec::err_buf(); }
 const char* ec_version(void) { return "marl_amd 0.4 (gfx950)"; }

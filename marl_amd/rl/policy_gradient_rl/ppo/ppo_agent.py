@@ -1,0 +1,161 @@
+"""PPO learner with the reference's agent interface (rl/policy_gradient_rl/ppo/ppo_agent.py:15-145):
+.buffer, .select_actions(obs, avail, test_mode), .train(), .save_models/.load_models.
+
+Same mathematics, step for step (:85-134): whole-batch reward normalisation with the unbiased std,
+old log-probs, critic values of obs/next_obs, GAE (the HIP reverse scan instead of the T-step torch loop),
+then `epochs` full-batch updates of critic (masked MSE) and actor (clipped surrogate + entropy bonus) with
+grad-norm clipping, Adam and a StepLR stepped once per epoch.
+
+Data-parallel form: with torch.distributed initialised, every rank holds its own shard of environments;
+loss numerators and `masks.sum()` are reduced over ranks (all-reduce of a few scalars), gradients are
+all-reduced as ONE flat buffer per optimiser step (RCCL over xGMI: <=25 KB, latency bound), and the
+clipping/optimiser step then runs identically on every rank.
+"""
+import torch as th
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch.distributions import Categorical
+from torch.optim import Adam
+
+from marl_amd.buffer.episode_buffer import EpisodeBuffer
+from marl_amd.rl.policy_gradient_rl.ppo.ppo_network import Actor, Critic
+from marl_amd.utils.action_selectors import greedy_selector, soft_selector
+from marl_amd.utils.advantage_utils import get_gae
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def all_reduce_sum_(t):
+    if _dist_on():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def all_reduce_grads_(params):
+    """Sum gradients over ranks with a single flat all-reduce."""
+    if not _dist_on():
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = th.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+def global_mean_std(x, eps_count=1):
+    """mean and UNBIASED std over all ranks' elements, as tensor.mean()/tensor.std() of the concatenation."""
+    n = th.tensor([float(x.numel())], device=x.device, dtype=th.float64)
+    s = x.double().sum().reshape(1)
+    all_reduce_sum_(n)
+    all_reduce_sum_(s)
+    mean = s / n
+    ss = ((x.double() - mean) ** 2).sum().reshape(1)
+    all_reduce_sum_(ss)
+    std = th.sqrt(ss / (n - 1))
+    return mean.float(), std.float()
+
+
+class PPOAgent:
+    def __init__(self, args):
+        self.device = th.device("cuda" if th.cuda.is_available() else "cpu")
+        self.args = args
+        self.actor = Actor(args).to(self.device)
+        self.critic = Critic(args).to(self.device)
+        if _dist_on():  # identical initial parameters on every rank
+            for p in list(self.actor.parameters()) + list(self.critic.parameters()):
+                dist.broadcast(p.data, src=0)
+        kw = dict(lr=args.lr)
+        if args.use_adm_epsilon:
+            kw["eps"] = args.adam_epsilon
+        self.actor_optimizer = Adam(params=self.actor.parameters(), **kw)
+        self.critic_optimizer = Adam(params=self.critic.parameters(), **kw)
+        self.actor_lr_scheduler = th.optim.lr_scheduler.StepLR(self.actor_optimizer, step_size=args.lr_decay_step,
+                                                               gamma=args.lr_decay_gamma)
+        self.critic_lr_scheduler = th.optim.lr_scheduler.StepLR(self.critic_optimizer, step_size=args.lr_decay_step,
+                                                                gamma=args.lr_decay_gamma)
+        self.buffer = EpisodeBuffer(args, device=self.device)
+        self._eye = th.eye(args.n_agents, device=self.device)
+        self.last_losses = {}
+
+    def _with_ids(self, obs):
+        ids = self._eye.expand(*obs.shape[:-2], -1, -1)
+        return th.cat([obs, ids], dim=-1)
+
+    @th.no_grad()
+    def select_actions(self, obs, avail_actions, test_mode=False):
+        test_mode = False  # the reference's PPO always samples (ppo_agent.py:62)
+        obs = self._with_ids(obs.to(self.device))
+        avail_actions = avail_actions.to(self.device)
+        actor_outs = self.actor(obs)
+        actor_outs[avail_actions == 0] = -1e10
+        return greedy_selector(actor_outs) if test_mode else soft_selector(actor_outs)
+
+    def evaluate_actions(self, inputs, avail_actions, actions):
+        actor_outs = self.actor(inputs)
+        actor_outs = actor_outs.masked_fill(avail_actions == 0, -1e10)
+        dist_ = Categorical(F.softmax(actor_outs, dim=-1))
+        return dist_.log_prob(actions.squeeze(-1)).unsqueeze(-1), dist_.entropy().unsqueeze(-1)
+
+    def train(self):
+        a = self.args
+        obs, avail_actions, actions, rewards, masks, next_obs = self.buffer.sample()
+        obs = self._with_ids(obs)
+        next_obs = self._with_ids(next_obs)
+        if a.normalize_rewards:
+            mean, std = global_mean_std(rewards)
+            rewards = (rewards - mean) / (std + 1e-5)
+        with th.no_grad():
+            old_log_pi_taken, _ = self.evaluate_actions(obs, avail_actions, actions)
+            old_v = self.critic(obs)
+            old_next_v = self.critic(next_obs)
+            advantages = get_gae(a, rewards, old_v, old_next_v, masks)
+            if a.normalize_advantages:
+                mean, std = global_mean_std(advantages)
+                advantages = (advantages - mean) / (std + 1e-5)
+            targets = advantages + old_v
+            denom = all_reduce_sum_(masks.sum().reshape(1).clone())
+        for _ in range(a.epochs):
+            log_pi_taken, entropy = self.evaluate_actions(obs, avail_actions, actions)
+            v = self.critic(obs)
+            critic_loss = (((v - targets) * masks) ** 2).sum() / denom
+
+            self.critic_optimizer.zero_grad()
+            critic_loss.backward()
+            all_reduce_grads_(list(self.critic.parameters()))
+            if a.use_grad_clip:
+                th.nn.utils.clip_grad_norm_(self.critic.parameters(), a.grad_norm_clip)
+            self.critic_optimizer.step()
+            self.critic_lr_scheduler.step()
+
+            ratios = th.exp(log_pi_taken - old_log_pi_taken)
+            surr1 = ratios * advantages
+            surr2 = th.clamp(ratios, 1 - a.eps_clip, 1 + a.eps_clip) * advantages
+            objective = th.min(surr1, surr2)
+            if a.use_entropy:
+                objective = objective + a.entropy_coef * entropy
+            actor_loss = -(objective * masks).sum() / denom
+
+            self.actor_optimizer.zero_grad()
+            actor_loss.backward()
+            all_reduce_grads_(list(self.actor.parameters()))
+            if a.use_grad_clip:
+                th.nn.utils.clip_grad_norm_(self.actor.parameters(), a.grad_norm_clip)
+            self.actor_optimizer.step()
+            self.actor_lr_scheduler.step()
+        self.last_losses = {"critic_loss": critic_loss.detach(), "actor_loss": actor_loss.detach()}
+
+    def save_models(self, path):
+        th.save(self.actor.state_dict(), "{}/actor.th".format(path))
+        th.save(self.critic.state_dict(), "{}/critic.th".format(path))
+
+    def load_models(self, path):
+        self.actor.load_state_dict(th.load("{}/actor.th".format(path), map_location=self.device, weights_only=True))
+        self.critic.load_state_dict(th.load("{}/critic.th".format(path), map_location=self.device, weights_only=True))
+
+    def load_offline_models(self, path):
+        self.load_models(path)

@@ -1,0 +1,85 @@
+"""`ParallelRunner` on the batched HIP environment.
+
+Same contract as the reference's runners/parallel_episode_runner.py:9-127 —
+`ParallelRunner(args, agent)`, `.run(test_mode) -> episode_info`, `.t_env`, `.close_env()` — but the
+n_threads worker processes, their pipes and the four pickle round-trips per env per step are replaced by ONE
+device-resident batch: per step the policy acts on device tensors, `ec_step` advances all environments and
+writes the next observation in the same launch, and the transition is copied device-to-device into the
+agent's buffer.  Env e of the batch is the reference's worker e (seeds task_seed+e, failure_seed+e, :19-20).
+
+Multi-GPU: each rank constructs the runner with its own `args.ec_env_id_base` shard; episode metrics are
+summed over ranks so that `episode_info` is the whole job's.
+"""
+import torch as th
+import torch.distributed as dist
+
+from marl_amd.envs.env_register import env_register
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class ParallelRunner:
+    def __init__(self, args, agent):
+        self.args = args
+        self.agent = agent
+        env_cls = env_register["edge_computing_batched"]
+        self.env = env_cls(args, n_envs=args.n_threads, env_id_base=getattr(args, "ec_env_id_base", 0))
+        self.t_env = 0
+        B, N = args.n_threads, args.n_agents
+        dev = self.env.device
+        self._obs = th.empty(B, N, args.obs_shape, dtype=th.float, device=dev)
+        self._avail = th.empty(B, N, args.n_actions, dtype=th.int, device=dev)
+        self._totals = th.zeros(6, dtype=th.float64, device=dev)
+
+    def run(self, test_mode=False):
+        args, env = self.args, self.env
+        B, N = args.n_threads, args.n_agents
+        self.agent.buffer.reset()
+        env.reset()
+        env.observe()
+        self._totals.zero_()
+        # all environments of the batch terminate together at episode_limit (edge_computing_env.py:139-142)
+        for t in range(args.episode_limit):
+            self._obs.copy_(env.obs)
+            self._avail.copy_(env.avail)
+            if args.algo_type == "rl":
+                actions = self.agent.select_actions(self._obs, self._avail, test_mode)
+            else:
+                actions = self.agent.select_actions(env)
+            reward, terminated, info = env.step(actions, want_hops=(t == args.episode_limit - 1))
+            # accumulate the episode statistics on device (parallel_episode_runner.py:94-99)
+            self._totals[0] += reward.double().sum()
+            self._totals[1] += info["task_completion_time"].double().sum()
+            self._totals[2:6] += info["counters"].double().sum(0)
+            if not test_mode:
+                self.t_env += B
+                rewards = reward.view(B, 1, 1).expand(B, N, 1)                     # team reward broadcast, :101
+                masks = (1 - terminated.float()).view(B, 1, 1).expand(B, N, 1)    # :102
+                self.agent.buffer.insert(self._obs, self._avail, actions.unsqueeze(-1), rewards, masks, env.obs)
+        env.check_status()
+        totals = self._totals.clone()
+        n_envs = th.tensor([float(B)], dtype=th.float64, device=totals.device)
+        hops = env.hop_hist.double().sum(0)
+        if _dist_on():
+            dist.all_reduce(totals)
+            dist.all_reduce(n_envs)
+            dist.all_reduce(hops)
+        ret, ctime, fin, succ, drop, fail = totals.tolist()
+        episode_info = {
+            "episode_return": ret / n_envs.item(),
+            "success_rate": succ / fin if fin else 0.0,
+            "drop_rate": drop / fin if fin else 0.0,
+            "failure_rate": fail / fin if fin else 0.0,
+            "task_completion_time": ctime / (succ + drop) if (succ + drop) else 0.0,
+            # the reference's parallel runner omits this key although run_utils.test_models reads it
+            # (run_utils.py:308); cumulative, as edge_node.py:82 never clears it
+            "max_hop_dict": {h: int(c) for h, c in enumerate(hops.tolist()) if c},
+        }
+        if not test_mode:
+            self.agent.train()
+        return episode_info
+
+    def close_env(self):
+        self.env.close()

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Phase breakdown of ec_step from the EC_STAMPS diagnostic build (MARL_AMD_LIB must point to it)."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch as th  # noqa: E402
+
+from marl_amd import _abi  # noqa: E402
+from marl_amd.envs.edge_computing.multihop.edge_computing_env import BatchedEdgeComputingEnv  # noqa: E402
+from tests.util import make_args  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+ns = make_args(["--task_size_max=6000"])
+env = BatchedEdgeComputingEnv(ns, n_envs=B)
+L = _abi.lib()
+L.ec_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+act = th.empty(B, 10, dtype=th.int64, device=env.device)
+env.reset()
+env.observe()
+names = ["entry->staged", "offload", "fail window", "tick0", "tick1", "ticks 2..9", "reduce", "generate+writeback",
+         "coop refill", "observe"]
+acc = []
+for t in range(160):
+    env.random_actions(seed=0, counter=t, out=act)
+    env.step(act)
+    if t >= 60 and t % 10 == 0:
+        nb = env.info_geometry()["B"] // env.info_geometry()["envs_per_block"] + 1
+        buf = np.zeros((nb + 8) * 16, dtype=np.uint64)
+        n = C.c_int64()
+        L.ec_debug_stamps(env._h, buf.ctypes.data_as(C.c_void_p), C.byref(n))
+        s = buf[: n.value * 16].reshape(n.value, 16).astype(np.int64)
+        seg = np.stack([s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 9] - s[:, 3], s[:, 10] - s[:, 9],
+                        s[:, 4] - s[:, 10], s[:, 5] - s[:, 4], s[:, 6] - s[:, 5], s[:, 7] - s[:, 6], s[:, 8] - s[:, 7]], 1)
+        span = (s[:, 8].max() - s[:, 0].min())
+        acc.append((seg.mean(0), seg.max(0), span, (s[:, 8] - s[:, 0]).mean(), s[:, 0].max() - s[:, 0].min()))
+m = np.mean([a[0] for a in acc], 0) / 100.0  # wall_clock64 ticks at 100 MHz -> us
+mx = np.mean([a[1] for a in acc], 0) / 100.0
+print("epb", env.info_geometry()["envs_per_block"], "blocks span %.1f us, mean block %.1f us, start skew %.1f us" % (
+    np.mean([a[2] for a in acc]) / 100.0, np.mean([a[3] for a in acc]) / 100.0, np.mean([a[4] for a in acc]) / 100.0))
+for nm, a, b in zip(names, m, mx):
+    print("  %-20s mean %6.2f us   max-block %6.2f us" % (nm, a, b))
