@@ -139,6 +139,45 @@ int ec_info(ec_handle h, int64_t* info_host, int32_t n);
 int ec_gae(const float* r, const float* v, const float* nv, const float* m, float* adv, int64_t B, int64_t T,
            int64_t N, float gamma, float gamma_lambda, void* stream);
 
+/* --- small fp32 MLPs of the rollout / reward path ----------------------------------------------------------
+ * Weights are torch nn.Linear layout [out][in] f32 contiguous on the device; hidden must be 64
+ * (ppo_config.py:6 / dgail_config.py hidden_dim).  Floating point: results agree with torch fp32 to 1e-5
+ * relative (different summation order), not bitwise. */
+
+/* Actor forward for `rows` = B*n_agents rows (row r is agent r % n_agents): replaces
+ * rl/policy_gradient_rl/ppo/ppo_network.py:21-25 + ppo_agent.py:61-74 (and dgail_network.py:6-19 +
+ * dgail_agent.py:114-126): input = (obs[9] | one-hot agent id), masked logits (-1e10 where avail == 0),
+ * softmax, and the action: inverse-CDF draw with the caller's uniforms[rows] in [0,1) (multinomial of
+ * action_selectors.py:11-16 with the randomness injected) or, uniforms == NULL, the first arg-max
+ * (action_selectors.py:18-20).  avail may be NULL (no mask); logits/probs [rows,n_actions] and
+ * actions [rows] i64 are each optional (NULL to skip).  n_actions <= 64. */
+int ec_policy_forward(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                      const float* b3, const float* obs, const int32_t* avail, const float* uniforms, int64_t rows,
+                      int32_t n_agents, int32_t n_actions, int32_t hidden, float* logits, float* probs,
+                      int64_t* actions, void* stream);
+
+/* GAIL discriminator reward: replaces dgail_network.py:37-50 + gail_agent.py / dgail_agent.py:482-485,501-518.
+ *   p = sigmoid(MLP(obs | one-hot action)); out = -log(1 - clamp(p, 1e-8, 1-1e-8)) * weight
+ *       (+ env_coef * env_reward[r] when env_reward != NULL).  prob [rows] optional (unclamped p). */
+int ec_gail_reward(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                   const float* obs, const int64_t* actions, const float* env_reward, int64_t rows, int32_t n_actions,
+                   int32_t hidden, float weight, float env_coef, float* prob, float* out, void* stream);
+
+/* DGAIL diffusion-discriminator reward: replaces DiffusionDiscriminator.compute_loss for c = expert and
+ * c = agent (dgail_network.py:71-108) and dgail_agent.py:487-499.  The reference draws (t, noise) inside
+ * compute_loss; here the caller passes them (t_* u8 [rows] in {0,1}, noise_* f32 [rows, 9+n_actions]) so that
+ * the result is a function of its inputs.  w1 [64][9+n_actions+128] and w2 are the EFFECTIVE (spectrally
+ * normalised) weights, w3 [9+n_actions][64]; time_embed / cond_embed [2][64].  9+n_actions <= 64.
+ *   loss_c = mean_d (eps - noise)^2 + r1_lambda * |d sum(eps) / d x_t|^2      (analytic input gradient)
+ *   d_phi = e^-Le / (e^-Le + e^-La + 1e-8);  reward = -log(1 - d_phi + 1e-8)
+ * loss_expert, loss_agent, d_phi, reward: [rows] f32, each optional. */
+int ec_diffusion_reward(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                        const float* b3, const float* time_embed, const float* cond_embed, const float* obs,
+                        const int64_t* actions, const uint8_t* t_expert, const float* noise_expert,
+                        const uint8_t* t_agent, const float* noise_agent, int64_t rows, int32_t n_actions,
+                        int32_t hidden, float r1_lambda, float* loss_expert, float* loss_agent, float* d_phi,
+                        float* reward, void* stream);
+
 const char* ec_last_error(void);
 const char* ec_version(void);
 

@@ -1,0 +1,237 @@
+"""Parity of the three fp32 MLP entry points (ec_policy_forward, ec_gail_reward, ec_diffusion_reward) against
+torch evaluated on the CPU in float64 (the "plain torch reference" of a floating-point kernel; float64 so that the
+reference's own rounding does not eat the tolerance).  Tolerance: 1e-5 relative (+2e-6 absolute for values that
+cancel to near zero), as the north star states for floating point.
+
+The torch modules are the package's own mirrors of the reference networks (ppo_network.py:6-47,
+dgail_network.py:6-108); the (t, noise) draws of DiffusionDiscriminator.compute_loss are injected on both sides.
+"""
+import argparse
+import copy
+
+import numpy as np
+import pytest
+import torch as th
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 2e-6
+
+
+def _dev():
+    if not th.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return th.device("cuda:0")
+
+
+def _close(got, want, what, rtol=RTOL, atol=ATOL):
+    got = got.detach().cpu().double().numpy()
+    want = want.detach().cpu().double().numpy()
+    assert got.shape == want.shape, what
+    err = np.abs(got - want)
+    tol = atol + rtol * np.abs(want)
+    bad = err > tol
+    assert not bad.any(), "%s: %d/%d beyond tolerance, worst err %.3e at want %.6e" % (
+        what, bad.sum(), bad.size, err[bad].max(), want[bad][np.argmax(err[bad])])
+
+
+def _obs(rows, gen):
+    # observation-like magnitudes: queue lengths up to tens, rates/probabilities in [0,1]
+    o = th.rand(rows, 9, generator=gen)
+    o[:, 0] *= 30.0
+    o[:, 3] *= 8.0
+    return o
+
+
+def _actor(n_agents, n_actions, seed):
+    from marl_amd.rl.policy_gradient_rl.ppo.ppo_network import Actor
+    th.manual_seed(seed)
+    args = argparse.Namespace(obs_shape=9, n_agents=n_agents, n_actions=n_actions, hidden_dim=64, activate_fun="relu",
+                              use_orthogonal_init=True)
+    net = Actor(args)
+    with th.no_grad():
+        net.fc3.weight.mul_(60.0)  # gain 0.01 leaves logits ~0; spread them so that softmax is not flat
+        for p in (net.fc1.bias, net.fc2.bias, net.fc3.bias):
+            p.uniform_(-0.3, 0.3)
+    return net
+
+
+@pytest.mark.parametrize("n_agents,rows", [(10, 1), (10, 63), (10, 64), (10, 65), (10, 40960), (40, 4000), (3, 1000)])
+def test_policy_forward(n_agents, rows):
+    from marl_amd.utils import mlp_device
+    dev = _dev()
+    A = n_agents + 1
+    net = _actor(n_agents, A, 11 + n_agents)
+    gen = th.Generator().manual_seed(rows)
+    obs = _obs(rows, gen)
+    avail = (th.rand(rows, A, generator=gen) < 0.6).to(th.int32)
+    avail[:, 0] = 1  # local execution is always available (edge_node.py get_avail_actions)
+    u = th.rand(rows, generator=gen)
+
+    ids = th.eye(n_agents, dtype=th.float64)[th.arange(rows) % n_agents]
+    ref = copy.deepcopy(net).double()
+    with th.no_grad():
+        logits = ref(th.cat([obs.double(), ids], dim=-1))
+    logits[avail == 0] = -1e10
+    probs = th.softmax(logits, dim=-1)
+
+    params = mlp_device.linear_params(net.to(dev))
+    lg, pr, act = mlp_device.policy_forward(params, obs.to(dev), n_agents, avail.to(dev), u.to(dev), want_logits=True)
+    th.cuda.synchronize()
+    _close(lg, logits, "logits")
+    _close(pr, probs, "probs")
+    act = act.cpu()
+    assert (avail[th.arange(rows), act] == 1).all(), "a masked action was drawn"
+    cdf = th.cumsum(probs, dim=-1)
+    want = th.minimum((cdf <= u.double()[:, None]).sum(-1), th.tensor(A - 1))
+    diff = act != want
+    if diff.any():  # only where u sits within rounding of a CDF boundary
+        lo = th.where(act > 0, cdf[th.arange(rows), (act - 1).clamp(min=0)], th.zeros(rows, dtype=th.float64))
+        hi = cdf[th.arange(rows), act]
+        slack = 1e-5
+        ok = (u.double() >= lo - slack) & (u.double() <= hi + slack)
+        assert ok[diff].all(), "sampled action off the inverse CDF"
+        assert diff.sum() <= max(2, rows // 2000)
+
+    # greedy + no mask
+    lg2, pr2, act2 = mlp_device.policy_forward(params, obs.to(dev), n_agents, None, None, want_logits=True)
+    with th.no_grad():
+        free = ref(th.cat([obs.double(), ids], dim=-1))
+    _close(lg2, free, "unmasked logits")
+    top2 = free.topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert (act2.cpu()[clear] == free.argmax(-1)[clear]).all()
+
+
+def test_policy_forward_outputs_optional_and_errors():
+    from marl_amd import _abi
+    from marl_amd.utils import mlp_device
+    dev = _dev()
+    net = _actor(10, 11, 3).to(dev)
+    params = mlp_device.linear_params(net)
+    obs = _obs(128, th.Generator().manual_seed(0)).to(dev)
+    lg, pr, act = mlp_device.policy_forward(params, obs, 10, want_logits=False, want_probs=False, want_actions=True)
+    assert lg is None and pr is None and act.shape == (128,)
+    lg, pr, act = mlp_device.policy_forward(params, obs[:0], 10)
+    assert pr.shape == (0, 11)
+    with pytest.raises(ValueError):
+        mlp_device.policy_forward(params, obs, 9)
+    bad = tuple(th.zeros(32, 32, device=dev) if i == 2 else p for i, p in enumerate(params))
+    with pytest.raises(_abi.EcError):
+        mlp_device.policy_forward(bad, obs, 10)
+
+
+@pytest.mark.parametrize("n_actions,rows", [(11, 1), (11, 130), (11, 40960), (41, 5000)])
+def test_gail_reward(n_actions, rows):
+    from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import GAILDiscriminator
+    from marl_amd.utils import mlp_device
+    dev = _dev()
+    th.manual_seed(5 + n_actions)
+    net = GAILDiscriminator(9 + n_actions, 64)
+    with th.no_grad():
+        for p in net.parameters():
+            p.mul_(1.5)  # push some probabilities towards the clamps
+    gen = th.Generator().manual_seed(rows)
+    obs = _obs(rows, gen)
+    actions = th.randint(0, n_actions, (rows,), generator=gen)
+    env_r = th.randn(rows, generator=gen) * 5.0
+    ref = copy.deepcopy(net).double()
+    with th.no_grad():
+        sa = th.cat([obs.double(), th.eye(n_actions, dtype=th.float64)[actions]], dim=-1)
+        p = ref(sa).squeeze(-1)
+    params = mlp_device.linear_params(net.to(dev))
+    out, prob = mlp_device.gail_reward(params, obs.to(dev), actions.to(dev), n_actions, weight=0.7, want_prob=True)
+    th.cuda.synchronize()
+    _close(prob, p, "D(s,a)", atol=1e-6)
+    # the reward is -log(1 - p): its condition number blows up as p -> 1, so compare where fp32 can resolve 1 - p
+    base = -th.log(1.0 - p.clamp(1e-8, 1 - 1e-8))
+    ok = p < 0.999
+    if ok.any():
+        _close(out.cpu()[ok], (base * 0.7)[ok], "reward", rtol=2e-4, atol=1e-5)
+    # saturated rows: what fp32 torch gives for the same probabilities
+    p32 = prob.cpu()
+    want32 = -th.log(1.0 - p32.clamp(1e-8, 1 - 1e-8)) * 0.7
+    _close(out.cpu(), want32, "reward (fp32 tail)", rtol=1e-5, atol=1e-5)
+    # mixed with the environment reward (dgail_agent.py:515-516)
+    out2, _ = mlp_device.gail_reward(params, obs.to(dev), actions.to(dev), n_actions, weight=0.7, env_reward=env_r.to(dev),
+                                     env_coef=0.25)
+    _close(out2.cpu(), out.cpu() + 0.25 * env_r, "mixed reward", rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("n_actions,rows", [(11, 1), (11, 200), (11, 40960), (41, 3000), (23, 777)])
+def test_diffusion_reward(n_actions, rows):
+    from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import DiffusionDiscriminator
+    from marl_amd.utils import mlp_device
+    dev = _dev()
+    SA = 9 + n_actions
+    th.manual_seed(17 + n_actions)
+    net = DiffusionDiscriminator(SA, 64)
+    with th.no_grad():
+        net.mlp[4].weight.mul_(4.0)
+        for i in (0, 2, 4):
+            net.mlp[i].bias.uniform_(-0.5, 0.5)
+    net.eval()  # spectral norm: use the stored u/v (no power iteration during the comparison)
+    gen = th.Generator().manual_seed(rows)
+    obs = _obs(rows, gen)
+    obs[:, 0] /= 10.0
+    actions = th.randint(0, n_actions, (rows,), generator=gen)
+    t_e = th.randint(0, 2, (rows,), generator=gen)
+    t_a = th.randint(0, 2, (rows,), generator=gen)
+    n_e = th.randn(rows, SA, generator=gen)
+    n_a = th.randn(rows, SA, generator=gen)
+
+    ref = copy.deepcopy(net).double()
+    sa = th.cat([obs.double(), th.eye(n_actions, dtype=th.float64)[actions]], dim=-1)
+    # R1 weight raised from the reference's 1e-4 so that a wrong gradient cannot hide under the MSE
+    lam = 0.05
+    ref.R1_LAMBDA = lam
+    Le = ref.compute_loss(sa, th.ones(rows, dtype=th.long), t_e, n_e.double()).detach()
+    La = ref.compute_loss(sa, th.zeros(rows, dtype=th.long), t_a, n_a.double()).detach()
+    pe, pa = th.exp(-Le), th.exp(-La)
+    dphi = pe / (pe + pa + 1e-8)
+    reward = -th.log(1 - dphi + 1e-8)
+
+    net = net.to(dev)
+    params = mlp_device.linear_params(net.mlp)
+    got = mlp_device.diffusion_reward(params, net.time_embed.weight, net.cond_embed.weight, obs.to(dev), actions.to(dev),
+                                      n_actions, t_e.to(dev), n_e.to(dev), t_a.to(dev), n_a.to(dev), r1_lambda=lam)
+    th.cuda.synchronize()
+    _close(got[0], Le, "loss(expert)")
+    _close(got[1], La, "loss(agent)")
+    # D_phi and the reward divide / take logs of differences of the losses: compare where they are well conditioned,
+    # and everywhere against fp32 torch applied to the kernel's own losses
+    well = (dphi > 1e-4) & (dphi < 0.999)
+    if well.any():
+        _close(got[2].cpu()[well], dphi[well], "D_phi", rtol=1e-4, atol=1e-7)
+        _close(got[3].cpu()[well], reward[well], "reward", rtol=2e-3, atol=1e-6)
+    le32, la32 = got[0].cpu(), got[1].cpu()
+    d32 = th.exp(-le32) / (th.exp(-le32) + th.exp(-la32) + 1e-8)
+    _close(got[2], d32, "D_phi (fp32 of own losses)", rtol=1e-5, atol=1e-7)
+
+
+def test_diffusion_reward_reference_lambda():
+    """Same comparison at the reference's own R1 weight (dgail_network.py:106) through the default argument."""
+    from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import DiffusionDiscriminator
+    from marl_amd.utils import mlp_device
+    dev = _dev()
+    rows, n_actions = 2048, 11
+    SA = 9 + n_actions
+    th.manual_seed(99)
+    net = DiffusionDiscriminator(SA, 64).eval()
+    gen = th.Generator().manual_seed(1)
+    obs = _obs(rows, gen)
+    actions = th.randint(0, n_actions, (rows,), generator=gen)
+    t_e = th.randint(0, 2, (rows,), generator=gen)
+    t_a = th.randint(0, 2, (rows,), generator=gen)
+    n_e = th.randn(rows, SA, generator=gen)
+    n_a = th.randn(rows, SA, generator=gen)
+    ref = copy.deepcopy(net).double()
+    sa = th.cat([obs.double(), th.eye(n_actions, dtype=th.float64)[actions]], dim=-1)
+    Le = ref.compute_loss(sa, th.ones(rows, dtype=th.long), t_e, n_e.double()).detach()
+    La = ref.compute_loss(sa, th.zeros(rows, dtype=th.long), t_a, n_a.double()).detach()
+    net = net.to(dev)
+    got = mlp_device.diffusion_reward(mlp_device.linear_params(net.mlp), net.time_embed.weight, net.cond_embed.weight,
+                                      obs.to(dev), actions.to(dev), n_actions, t_e.to(dev), n_e.to(dev), t_a.to(dev),
+                                      n_a.to(dev))
+    _close(got[0], Le, "loss(expert)")
+    _close(got[1], La, "loss(agent)")
