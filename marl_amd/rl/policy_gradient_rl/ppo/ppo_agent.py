@@ -21,6 +21,7 @@ from marl_amd.buffer.episode_buffer import EpisodeBuffer
 from marl_amd.rl.policy_gradient_rl.ppo.ppo_network import Actor, Critic
 from marl_amd.utils.action_selectors import greedy_selector, soft_selector
 from marl_amd.utils.advantage_utils import get_gae
+from marl_amd.utils import mlp_device
 
 
 def _dist_on():
@@ -62,7 +63,8 @@ def global_mean_std(x, eps_count=1):
 
 class PPOAgent:
     def __init__(self, args):
-        self.device = th.device("cuda" if th.cuda.is_available() else "cpu")
+        # ppo_agent.py:17 picks cuda when present; `ec_force_device` lets the host-logic tests pin the CPU
+        self.device = th.device(getattr(args, "ec_force_device", None) or ("cuda" if th.cuda.is_available() else "cpu"))
         self.args = args
         self.actor = Actor(args).to(self.device)
         self.critic = Critic(args).to(self.device)
@@ -86,9 +88,23 @@ class PPOAgent:
         ids = self._eye.expand(*obs.shape[:-2], -1, -1)
         return th.cat([obs, ids], dim=-1)
 
+    def _fused_policy_ok(self):
+        a = self.args
+        return (self.device.type == "cuda" and a.activate_fun == "relu" and a.hidden_dim == 64 and a.obs_shape == 9
+                and a.n_actions <= 64)
+
     @th.no_grad()
     def select_actions(self, obs, avail_actions, test_mode=False):
         test_mode = False  # the reference's PPO always samples (ppo_agent.py:62)
+        if self._fused_policy_ok():
+            # one launch: one-hot agent id, 3-layer MLP, mask, softmax and the categorical draw
+            # (ec_policy_forward; the uniforms come from torch's device generator)
+            lead = obs.shape[:-1]
+            u = th.rand(obs.numel() // obs.shape[-1], device=self.device)
+            _, _, actions = mlp_device.policy_forward(mlp_device.linear_params(self.actor), obs.to(self.device),
+                                                      self.args.n_agents, avail_actions.to(self.device), u,
+                                                      want_probs=False)
+            return actions.view(lead)
         obs = self._with_ids(obs.to(self.device))
         avail_actions = avail_actions.to(self.device)
         actor_outs = self.actor(obs)
@@ -147,7 +163,9 @@ class PPOAgent:
                 th.nn.utils.clip_grad_norm_(self.actor.parameters(), a.grad_norm_clip)
             self.actor_optimizer.step()
             self.actor_lr_scheduler.step()
-        self.last_losses = {"critic_loss": critic_loss.detach(), "actor_loss": actor_loss.detach()}
+        # each rank holds its shard's share of the (globally normalised) losses: sum them for reporting
+        self.last_losses = {"critic_loss": all_reduce_sum_(critic_loss.detach().clone().reshape(1))[0],
+                            "actor_loss": all_reduce_sum_(actor_loss.detach().clone().reshape(1))[0]}
 
     def save_models(self, path):
         th.save(self.actor.state_dict(), "{}/actor.th".format(path))

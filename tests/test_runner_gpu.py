@@ -1,0 +1,143 @@
+"""ParallelRunner + PPOAgent on the batched HIP environment.
+
+  * the runner's episode_info against the same rollout stepped on the CPU oracle with the same (deterministic,
+    state-dependent) policy: counters exact, float aggregates to fp32 rounding of the per-step outputs;
+  * two PPO iterations end to end (rollout -> device buffer -> reward normalisation -> GAE kernel -> 4 epochs):
+    buffer contents consistent with the env's outputs, parameters move, losses finite, masked actions never taken.
+"""
+import numpy as np
+import pytest
+import torch as th
+
+from tests.util import args_from_golden, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+class _FirstNeighbourAgent:
+    """Stub with the agent interface: forwards to the lowest-numbered available action (local execution only when no
+    neighbour is available) - keeps multi-hop traffic high."""
+
+    class _Buf:
+        def reset(self):
+            pass
+
+        def insert(self, *a):
+            pass
+
+    def __init__(self):
+        self.buffer = self._Buf()
+        self.trained = 0
+
+    @staticmethod
+    def pick(avail):
+        return avail.to(th.int64).argmax(dim=-1)
+
+    def select_actions(self, obs, avail, test_mode=False):
+        return self.pick(avail)
+
+    def train(self):
+        self.trained += 1
+
+
+def _args(B, **over):
+    g = load_golden("env10")
+    a = args_from_golden(g)
+    a.n_threads = B
+    a.algo_type = "rl"
+    a.obs_shape = 9
+    a.n_agents = a.edge_node_num
+    a.n_actions = a.edge_node_num + 1
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_runner_episode_info_matches_oracle(oracle_lib):
+    from marl_amd import _abi
+    from marl_amd.runners.runner_register import runner_register
+    from oracle.ec_oracle import OracleEnv
+    B, base = 96, 11
+    args = _args(B, ec_env_id_base=base, ec_hop_hist_len=32)
+    agent = _FirstNeighbourAgent()
+    runner = runner_register["parallel"](args, agent)
+    infos = [runner.run(test_mode=False), runner.run(test_mode=True)]
+    assert agent.trained == 1 and runner.t_env == B * args.episode_limit
+
+    orc = OracleEnv(_abi.config_from_args(args, hop_hist_len=32), runner.env.tables, B, env_id_base=base)
+    for ep in range(2):
+        orc.reset()
+        ret = ctime = 0.0
+        cnt = np.zeros(4, dtype=np.int64)
+        for t in range(args.episode_limit):
+            _, avail = orc.observe()
+            out = orc.step(avail.argmax(-1))
+            assert out["bad"] == 0
+            ret += float(out["reward"].astype(np.float32).astype(np.float64).sum())
+            ctime += float(out["completion_time"].astype(np.float32).astype(np.float64).sum())
+            cnt += out["counters"].sum(0)
+        fin, succ, drop, fail = [int(x) for x in cnt]
+        info = infos[ep]
+        assert fin > 0
+        assert info["success_rate"] == succ / fin and info["drop_rate"] == drop / fin and info["failure_rate"] == fail / fin
+        assert abs(info["episode_return"] - ret / B) <= 1e-9 * max(1.0, abs(ret / B))
+        assert abs(info["task_completion_time"] - ctime / (succ + drop)) <= 1e-9 * (ctime / (succ + drop))
+        hops = out["hop_hist"].sum(0)  # cumulative over episodes, as edge_node.py:82
+        assert info["max_hop_dict"] == {h: int(c) for h, c in enumerate(hops) if c}
+    runner.close_env()
+
+
+def test_ppo_two_iterations():
+    from marl_amd.agent_register import agent_register
+    from marl_amd.runners.runner_register import runner_register
+    B = 64
+    args = _args(B, episode_limit=40)
+    th.manual_seed(100)
+    agent = agent_register["ppo"](args)
+    assert agent.device.type == "cuda" and agent._fused_policy_ok()
+    runner = runner_register["parallel"](args, agent)
+    before = th.cat([p.detach().reshape(-1).clone() for p in agent.actor.parameters()])
+    info = runner.run(test_mode=False)
+    buf = agent.buffer
+    obs, avail, actions, rewards, masks, next_obs = buf.sample()
+    assert buf.can_sample() and runner.t_env == B * args.episode_limit
+    # transitions chain: next_obs[t] is obs[t+1]; the last mask is 0, all others 1 (parallel_episode_runner.py:102)
+    assert th.equal(next_obs[:, :-1], obs[:, 1:])
+    assert float(masks[:, -1].sum()) == 0 and float(masks[:, :-1].min()) == 1
+    # team reward broadcast over agents (:101)
+    assert th.equal(rewards, rewards[:, :, :1].expand_as(rewards))
+    # sampled actions respect the availability mask
+    assert bool((avail.gather(-1, actions) == 1).all())
+    after = th.cat([p.detach().reshape(-1) for p in agent.actor.parameters()])
+    assert not th.equal(before, after)
+    assert all(bool(th.isfinite(v)) for v in agent.last_losses.values())
+    for k in ("episode_return", "success_rate", "drop_rate", "failure_rate", "task_completion_time"):
+        assert np.isfinite(info[k])
+    assert abs(info["success_rate"] + info["drop_rate"] + info["failure_rate"] - 1.0) < 1e-12
+    info2 = runner.run(test_mode=False)
+    assert runner.t_env == 2 * B * args.episode_limit and np.isfinite(info2["episode_return"])
+    runner.close_env()
+
+
+def test_fused_select_actions_matches_torch_distribution():
+    """select_actions (HIP kernel, inverse CDF) draws from the same masked softmax as the reference's
+    Categorical path: compare empirical frequencies on a fixed state."""
+    from marl_amd.agent_register import agent_register
+    args = _args(4096)
+    th.manual_seed(5)
+    agent = agent_register["ppo"](args)
+    with th.no_grad():
+        agent.actor.fc3.weight.mul_(30.0)
+    N, A = args.n_agents, args.n_actions
+    obs1 = th.rand(1, N, 9, device=agent.device)
+    avail1 = (th.rand(1, N, A, device=agent.device) < 0.6).int()
+    avail1[..., 0] = 1
+    obs, avail = obs1.expand(4096, N, 9).contiguous(), avail1.expand(4096, N, A).contiguous()
+    acts = th.stack([agent.select_actions(obs, avail) for _ in range(8)])  # 32768 draws per agent
+    with th.no_grad():
+        logits = agent.actor(agent._with_ids(obs1))
+        logits[avail1 == 0] = -1e10
+        probs = th.softmax(logits, -1)[0]
+    freq = th.stack([(acts[..., n].reshape(-1, 1) == th.arange(A, device=acts.device)).float().mean(0) for n in range(N)])
+    assert float((freq - probs).abs().max()) < 0.012   # ~4 sigma at p=0.5, 32768 draws
+    assert float(freq[avail1[0] == 0].sum()) == 0.0
