@@ -39,6 +39,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
     p.add_argument("--roofline-steps", type=int, default=200)
     p.add_argument("--threads", type=int, default=0, help="override threads per block of the step kernel")
+    p.add_argument("--ppo-iters", type=int, default=3,
+                   help="also time this many PPO iterations (rollout + update) at N=1 and report them beside the metric")
     return p.parse_args()
 
 
@@ -149,6 +151,44 @@ def cpu_baseline(args_ns, tables, n_envs, budget_s):
             "sample": "%d envs x %d steps (observe + random policy + step), OpenMP C oracle, %.1f s" % (n_envs, steps, dt)}
 
 
+def ppo_iterations(ns, B, N, iters):
+    """BASELINE.json's second figure: wall time of one PPO iteration = ParallelRunner.run(test_mode=False):
+    episode_limit steps of (fused policy kernel -> ec_step -> device buffer insert) for all B envs, then
+    PPOAgent.train() (reward normalisation, GAE kernel, `epochs` full-batch actor/critic updates)."""
+    import torch as th
+    from marl_amd.agent_register import agent_register
+    from marl_amd.runners.runner_register import runner_register
+    ns.n_threads, ns.algo_type, ns.obs_shape, ns.n_agents, ns.n_actions = B, "rl", 9, N, N + 1
+    th.manual_seed(100)
+    agent = agent_register["ppo"](ns)
+    runner = runner_register["parallel"](ns, agent)
+    train = agent.train
+    spans = []
+
+    def timed_train():
+        th.cuda.synchronize()
+        t0 = time.perf_counter()
+        train()
+        th.cuda.synchronize()
+        spans.append(time.perf_counter() - t0)
+
+    agent.train = timed_train
+    total = []
+    for it in range(iters + 1):  # first iteration is warm-up (allocator, kernel load)
+        th.cuda.synchronize()
+        t0 = time.perf_counter()
+        runner.run(test_mode=False)
+        th.cuda.synchronize()
+        total.append(time.perf_counter() - t0)
+    runner.close_env()
+    total, upd = sorted(total[1:]), sorted(spans[1:])
+    med = lambda v: v[len(v) // 2]
+    return {"total_ms": 1e3 * med(total), "update_ms": 1e3 * med(upd), "rollout_ms": 1e3 * (med(total) - med(upd)),
+            "iters": iters, "envs": B, "agents": N, "episode_limit": ns.episode_limit, "epochs": ns.epochs,
+            "rows_per_update": B * N * ns.episode_limit,
+            "rollout_agent_steps_per_s": B * N * ns.episode_limit / (med(total) - med(upd))}
+
+
 def main():
     a = parse()
     import torch as th
@@ -218,6 +258,9 @@ def main():
         if a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(ns, env.tables, B, a.cpu_seconds)
     env.close()
+    if rank == 0 and world == 1 and a.ppo_iters > 0:
+        del roll
+        out["ppo_iteration"] = ppo_iterations(ns, B, N, a.ppo_iters)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

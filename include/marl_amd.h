@@ -115,6 +115,13 @@ int ec_step(ec_handle h, const int64_t* actions, float* reward, uint8_t* termina
 int ec_random_policy(const int32_t* avail, int64_t rows, int32_t n_actions, uint64_t seed, uint64_t counter,
                      uint64_t* counter_dev, int64_t* actions, void* stream);
 
+/* The expert of the GAIL / DGAIL runners for every env of the handle: OptimalAgent.get_current_optimal_action
+ * (optimal/optimal_agent.py:102-120) = _conservative_action_selection at conservativeness 1.0 (:166-209) with the
+ * reliability / time-margin / load / efficiency scores of :211-375, evaluated on the device state instead of walking
+ * env.edge_nodes[i] Python objects.  avail [B,N,N+1] i32 is the mask of the same state (ec_observe / ec_step);
+ * actions [B,N] i64. */
+int ec_expert_policy(ec_handle h, const int32_t* avail, int64_t* actions, void* stream);
+
 /* Device status word (EC_ST_* bits, sticky until cleared). Synchronises the stream. */
 int ec_status(ec_handle h, uint32_t* status_host, int clear, void* stream);
 

@@ -142,6 +142,7 @@ def lib():
     L.ec_observe.argtypes = [vp, vp, vp, vp]
     L.ec_step.argtypes = [vp] + [vp] * 8 + [vp]
     L.ec_random_policy.argtypes = [vp, i64, i32, u64, u64, vp, vp, vp]
+    L.ec_expert_policy.argtypes = [vp, vp, vp, vp]
     L.ec_status.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, vp]
     L.ec_debug_dump.argtypes = [vp, i64, vp, i64, C.POINTER(i64)]
     L.ec_debug_rng_cursors.argtypes = [vp, vp]
@@ -154,7 +155,7 @@ def lib():
     L.ec_diffusion_reward.argtypes = [vp] * 14 + [i64, i32, i32, f32, vp, vp, vp, vp, vp]
     for fn in ("ec_create", "ec_destroy", "ec_reset", "ec_observe", "ec_step", "ec_random_policy", "ec_status",
                "ec_debug_dump", "ec_debug_rng_cursors", "ec_debug_live_tasks", "ec_info", "ec_gae",
-               "ec_policy_forward", "ec_gail_reward", "ec_diffusion_reward"):
+               "ec_policy_forward", "ec_gail_reward", "ec_diffusion_reward", "ec_expert_policy"):
         getattr(L, fn).restype = C.c_int
     L.ec_last_error.restype = C.c_char_p
     L.ec_version.restype = C.c_char_p

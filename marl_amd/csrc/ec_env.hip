@@ -125,6 +125,9 @@ struct EcDev {
     const double* rate;       // [N][N]
     const uint8_t* adj;       // [N][A]
     const u64* adj_bits;      // [N] adj rows as bit masks (N <= 64), else null
+    const double* efr;        // [N] execution failure rates (expert policy)
+    const double* tfr;        // [N][N] link failure rates (expert policy)
+    const int* cores;         // [N]
     // per-lane state
     u32* mt;        // [2][P][MT_STRIDE]
     u32* rng_pos;   // [2][P] next word to consume
@@ -1430,6 +1433,83 @@ __global__ void k_random_policy(const int32_t* __restrict__ avail, int64_t rows,
 }
 
 // parity-test helper: one thread serialises env `env`
+// ------------------------------------------------------------------------------------------ expert policy
+// OptimalAgent._calculate_conservative_score (optimal/optimal_agent.py:211-258) with its four terms (:260-375), in
+// the reference's evaluation order (this file is built without FMA contraction).
+__device__ __forceinline__ double expert_score(const EcDev& d, int64_t env_base, int s, int t, double size, double cycles,
+                                               double cons) {
+    const double exec_t = cycles / d.cap[t];
+    double rel = exp(-d.efr[t] * exec_t);  // :260-289
+    double trans_t = 0.0;
+    if (s != t) {
+        trans_t = size / d.rate[s * d.N + t];
+        rel = exp(-d.tfr[s * d.N + t] * trans_t) * rel;
+    }
+    if (rel < 0.85) rel = fmax(0.0, rel - 5.0 * (0.85 - rel));
+    const int nwait = (int)d.wq_len[env_base + t], nexec = (int)d.ex_n[env_base + t];
+    const double qf = 1.5 * cons;  // :291-328
+    const double waiting = nwait * exec_t * qf / (d.k > 1 ? d.k : 1);
+    const double total = (s == t) ? exec_t + waiting : trans_t + exec_t + waiting;
+    const double margin = d.deadline - total;
+    const double required = d.deadline * 0.4 * cons;
+    double time_score = 0.0;
+    if (!(margin < required)) {
+        time_score = fmin(1.0, margin / d.deadline);
+        if (time_score < 0.5) time_score *= 3.0;
+    }
+    const int cur = nwait + nexec;  // :330-353
+    const double max_load = (d.qlen[t] + d.k) * 0.7;
+    double load = 0.0;
+    if (!(cur >= max_load)) {
+        load = 1.0 - cur / max_load;
+        if (cur > 0) load = fmax(0.0, load - cur * 0.2);
+    }
+    const double opt = d.dt * 3;  // :355-375
+    double eff = exec_t <= opt ? 1.0 : fmax(0.2, opt / exec_t);
+    eff += fmin(0.2, d.cores[t] / 32.0);
+    eff = fmin(1.0, eff);
+    if (rel < 0.85) return -INFINITY;  // :235-239
+    if (time_score == 0) return -INFINITY;
+    const double bonus = (s == t) ? 0.3 * cons : 0.0;
+    return 0.6 * rel + 0.25 * time_score + 0.1 * load + 0.05 * eff + bonus;
+}
+
+// OptimalAgent.get_current_optimal_action -> _conservative_action_selection(env, 1.0) (optimal_agent.py:102-120,166-209)
+__global__ void k_expert(EcDev d, const int32_t* __restrict__ avail, int64_t* __restrict__ actions) {
+    const int64_t lane = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= d.P) return;
+    const int64_t env = lane / d.N;
+    const int i = (int)(lane - env * d.N);
+    const int64_t base = env * d.N;
+    const int32_t* a = avail + lane * d.A;
+    int last = -1;
+    for (int j = 0; j < d.A; j++)
+        if (a[j]) last = j;
+    if (last < 0 || !d.has_new[lane]) {
+        actions[lane] = last >= 0 ? last : d.N;
+        return;
+    }
+    const Rec nt = load_rec(d.newt + lane);
+    int best = last;
+    double best_score = -INFINITY;
+    if (a[i]) {
+        const double sc = expert_score(d, base, i, i, nt.size, nt.cycles, 1.0);
+        if (sc > best_score) {
+            best_score = sc;
+            best = i;
+        }
+    }
+    for (int j = 0; j < last; j++) {  // available_indices[:-1]: every available index but the last one
+        if (!a[j] || j >= d.N || j == i) continue;
+        const double sc = expert_score(d, base, i, j, nt.size, nt.cycles, 1.0);
+        if (sc > best_score + 0.1 * 1.0) {
+            best_score = sc;
+            best = j;
+        }
+    }
+    actions[lane] = best;
+}
+
 __global__ void k_dump(EcDev d, int64_t env, double* rows, int64_t max_rows, int64_t* n_rows) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     int64_t r = 0;
@@ -1653,6 +1733,8 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     }
     memcpy(rate.data(), topo->rate, sizeof(double) * N * N);
     memcpy(adj.data(), topo->adj, (size_t)N * (N + 1));
+    std::vector<double> efr(topo->efr, topo->efr + N), tfr(topo->tfr, topo->tfr + (size_t)N * N);
+    std::vector<int> cores(topo->cores, topo->cores + N);
 
     EC_TRY(dev_upload(h, &d.acc, acc));
     EC_TRY(dev_upload(h, &d.cap, cap));
@@ -1669,6 +1751,9 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     EC_TRY(dev_upload(h, &d.slot_of, slot_of));
     EC_TRY(dev_upload(h, &d.rate, rate));
     EC_TRY(dev_upload(h, &d.adj, adj));
+    EC_TRY(dev_upload(h, &d.efr, efr));
+    EC_TRY(dev_upload(h, &d.tfr, tfr));
+    EC_TRY(dev_upload(h, &d.cores, cores));
     d.adj_bits = nullptr;
     if (N <= 64) EC_TRY(dev_upload(h, &d.adj_bits, adj_bits));
 
@@ -1833,6 +1918,15 @@ int ec_random_policy(const int32_t* avail, int64_t rows, int32_t n_actions, uint
     if (rows == 0) return EC_OK;
     hipLaunchKernelGGL(k_random_policy, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, avail,
                        rows, (int)n_actions, seed, counter, counter_dev, actions);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+int ec_expert_policy(ec_handle h, const int32_t* avail, int64_t* actions, void* stream) {
+    if (!h || !avail || !actions) return ec::fail(EC_EINVAL, "ec_expert_policy: null argument");
+    EC_HIP(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_expert, dim3((unsigned)((h->d.P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->d, avail,
+                       actions);
     EC_HIP(hipGetLastError());
     return EC_OK;
 }

@@ -135,6 +135,14 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
                    "ec_random_policy")
         return out
 
+    def expert_actions(self, out=None):
+        """OptimalAgent.get_current_optimal_action (optimal/optimal_agent.py:102-120) for every env of the batch,
+        on the current device state; [B, N] int64."""
+        avail = self.get_avail_actions()
+        out = out if out is not None else th.empty(self.n_envs, self.n_agents, dtype=th.int64, device=self.device)
+        _abi.check(self.lib.ec_expert_policy(self._h, _ptr(avail), _ptr(out), self._stream()), "ec_expert_policy")
+        return out
+
     def live_tasks(self):
         n = C.c_int64()
         _abi.check(self.lib.ec_debug_live_tasks(self._h, C.byref(n)), "ec_debug_live_tasks")

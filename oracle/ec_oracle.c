@@ -459,6 +459,96 @@ int oc_observe(oc_handle E, double* obs, int32_t* avail) {
     return 0;
 }
 
+/* ---------------------------------------------------------------- expert (optimal/optimal_agent.py)
+ * OptimalAgent.get_current_optimal_action = _conservative_action_selection(env, conservativeness = 1.0)
+ * (optimal_agent.py:102-120,166-209) with the score terms of :211-375.  Python evaluation order throughout. */
+static double expert_score(const struct oc_env* E, const oc_one* env, int s, int t, const oc_task* task, double cons) {
+    const ec_config* c = &E->cfg;
+    const oc_node* tn = &env->nodes[t];
+    const int N = E->N;
+    /* reliability, :260-289 */
+    double exec_t = task->cycles / tn->cap;
+    double rel = exp(-tn->efr * exec_t);
+    double trans_t = 0.0;
+    if (s != t) {
+        trans_t = task->size / E->rate[s * N + t];
+        rel = exp(-E->tfr[s * N + t] * trans_t) * rel;
+    }
+    if (rel < 0.85) rel = fmax(0.0, rel - 5.0 * (0.85 - rel));
+    /* time margin, :291-328 */
+    double qf = 1.5 * cons;
+    double waiting = tn->execution.len * exec_t * qf / (c->k > 1 ? c->k : 1);
+    double total = (s == t) ? exec_t + waiting : trans_t + exec_t + waiting;
+    double margin = task->deadline - total;
+    double required = task->deadline * 0.4 * cons;
+    double time_score;
+    if (margin < required) {
+        time_score = 0.0;
+    } else {
+        time_score = fmin(1.0, margin / task->deadline);
+        if (time_score < 0.5) time_score *= 3.0;
+    }
+    /* load, :330-353 */
+    int cur = tn->execution.len + tn->executing.len;
+    double max_load = (tn->qlen + c->k) * 0.7;
+    double load;
+    if (cur >= max_load) {
+        load = 0.0;
+    } else {
+        load = 1.0 - cur / max_load;
+        if (cur > 0) load = fmax(0.0, load - cur * 0.2);
+    }
+    /* efficiency, :355-375 */
+    double opt = c->mini_time_slot * 3;
+    double eff = exec_t <= opt ? 1.0 : fmax(0.2, opt / exec_t);
+    eff += fmin(0.2, tn->cores / 32.0);
+    eff = fmin(1.0, eff);
+    /* feasibility + weighted sum, :235-255 */
+    if (rel < 0.85) return -INFINITY;
+    if (time_score == 0) return -INFINITY;
+    double bonus = (s == t) ? 0.3 * cons : 0.0;
+    return 0.6 * rel + 0.25 * time_score + 0.1 * load + 0.05 * eff + bonus;
+}
+
+/* avail [B,N,N+1] i32 (the mask the runner already holds), actions [B,N] i64 */
+int oc_expert_policy(oc_handle E, const int32_t* avail, int64_t* actions) {
+    const int N = E->N, A = N + 1;
+#pragma omp parallel for num_threads(E->n_threads) schedule(static)
+    for (int64_t e = 0; e < E->B; e++) {
+        const oc_one* env = &E->envs[e];
+        for (int i = 0; i < N; i++) {
+            const int32_t* a = avail + (e * N + i) * A;
+            int last = -1;
+            for (int j = 0; j < A; j++)
+                if (a[j]) last = j;
+            const oc_node* n = &env->nodes[i];
+            if (last < 0 || !n->has_new) {
+                actions[e * N + i] = last >= 0 ? last : N;
+                continue;
+            }
+            int best = last;
+            double best_score = -INFINITY;
+            if (a[i]) {
+                double sc = expert_score(E, env, i, i, &n->new_task, 1.0);
+                if (sc > best_score) {
+                    best_score = sc;
+                    best = i;
+                }
+            }
+            for (int j = 0; j < last; j++) { /* available_indices[:-1]: every available index but the last */
+                if (!a[j] || j >= N || j == i) continue;
+                double sc = expert_score(E, env, i, j, &n->new_task, 1.0);
+                if (sc > best_score + 0.1 * 1.0) {
+                    best_score = sc;
+                    best = j;
+                }
+            }
+            actions[e * N + i] = best;
+        }
+    }
+    return 0;
+}
+
 /* edge_computing_env.py:84-143.  reward / completion_time are fp64 (Python floats).
  * Returns the number of envs that hit the reference's ZeroDivisionError path. */
 int oc_step(oc_handle E, const int64_t* actions, double* reward, uint8_t* terminated, int32_t* counters,

@@ -44,6 +44,7 @@ def lib():
         L.oc_rng_task_draws.restype = None
         L.oc_gae.argtypes = [vp] * 5 + [i64] * 3 + [C.c_float, C.c_float]
         L.oc_random_policy.argtypes = [vp, i64, C.c_int32, C.c_uint64, C.c_uint64, vp]
+        L.oc_expert_policy.argtypes = [vp, vp, vp]
         L.oc_rollout_random.argtypes = [vp, i64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(i64)]
         _lib = L
     return _lib
@@ -123,6 +124,13 @@ class OracleEnv:
         hops = np.empty((self.B, self.H), dtype=np.int32) if want_hops else None
         bad = lib().oc_step(self._h, _p(a), _p(reward), _p(term), _p(counters), _p(ctime), _p(hops))
         return dict(reward=reward, terminated=term, counters=counters, completion_time=ctime, hop_hist=hops, bad=bad)
+
+    def expert_policy(self, avail):
+        """OptimalAgent.get_current_optimal_action for every env (optimal_agent.py:102-120)"""
+        a = np.ascontiguousarray(avail, dtype=np.int32).reshape(self.B, self.N, self.N + 1)
+        out = np.empty((self.B, self.N), dtype=np.int64)
+        lib().oc_expert_policy(self._h, _p(a), _p(out))
+        return out
 
     def step_fast(self, actions_ptr_arr):
         """bench leg: no output buffers beyond reward"""

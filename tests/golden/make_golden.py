@@ -16,6 +16,8 @@ Groups
   env10    default topology (N=10, task_size_max=6000): static tables + action replay
   env40    scaled topology (N=40): static tables + short action replay
   gae      utils/advantage_utils.py:4-9 on random inputs
+  expert10 / expert40   OptimalAgent.get_current_optimal_action (optimal/optimal_agent.py:102-120,166-375) on the
+           states of replayed trajectories (expert-driven and expert/random mixtures)
 """
 import argparse
 import os
@@ -99,12 +101,14 @@ def _policy(name, rng, env, avail):
             else:
                 cand = list(node.actions)
                 acts[i] = cand[rng.randint(len(cand))]
+        elif name in ("expert", "mixed"):
+            pass  # whole-env decision, see _replay
         else:
             raise KeyError(name)
     return acts
 
 
-def _replay(args, k, policy, episodes, snap_every, pol_seed):
+def _replay(args, k, policy, episodes, snap_every, pol_seed, expert=None):
     """ParallelRunner semantics for env k (parallel_episode_runner.py:17-21,40-113)."""
     import copy
     import numpy as np
@@ -125,7 +129,18 @@ def _replay(args, k, policy, episodes, snap_every, pol_seed):
         while True:
             obs = env.get_obs()
             avail = env.get_avail_actions()
-            acts = _policy(policy, rng, env, avail)
+            if expert is not None:
+                # the expert's decision for this state is recorded at EVERY step, whoever acts
+                ex = np.asarray(expert.get_current_optimal_action(env), dtype=np.int64)
+                direct = np.asarray(expert._conservative_action_selection(env, conservativeness=1.0), dtype=np.int64)
+                assert np.array_equal(ex, direct), "the reference fell back to its greedy path"
+                out.setdefault("expert_actions", []).append(ex)
+                if policy == "expert" or (policy == "mixed" and rng.random_sample() < 0.5):
+                    acts = ex
+                else:
+                    acts = _policy("random_valid", rng, env, avail)
+            else:
+                acts = _policy(policy, rng, env, avail)
             reward, terminated, info = env.step(acts)
             out["actions"].append(acts)
             out["obs"].append(np.asarray(obs, dtype=np.float64))
@@ -167,6 +182,8 @@ def _replay(args, k, policy, episodes, snap_every, pol_seed):
         "hop_hist": np.asarray(hop_hist, dtype=np.int64),
         "snap": np.asarray(snaps, dtype=np.float64).reshape(-1, 12),
     }
+    if expert is not None:
+        res["expert_actions"] = np.asarray(out["expert_actions"], dtype=np.int64)
     return res
 
 
@@ -272,6 +289,42 @@ def gen_env(tag):
     np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
 
 
+def gen_expert(tag):
+    import numpy as np
+    if tag == "expert10":
+        args = _ref_args(["--task_size_max=6000", "--seed=100"])
+        cases = [(0, "expert", 2), (5, "expert", 1), (0, "mixed", 2), (17, "mixed", 2)]
+    else:
+        args = _ref_args(["--task_size_max=6000", "--seed=100", "--edge_node_num=40"])
+        cases = [(0, "expert", 1), (2, "mixed", 1)]
+    out = {}
+    cfg_keys = ["episode_limit", "mini_time_slot", "mini_time_slot_num", "edge_node_num", "task_probability_min",
+                "task_probability_max", "task_size_min", "task_size_max", "task_complexity_min",
+                "task_complexity_max", "deadline", "single_core_cpu_capacity", "transmission_rate_min",
+                "transmission_rate_max", "execution_failure_rate_min", "execution_failure_rate_max",
+                "transmission_failure_rate_min", "transmission_failure_rate_max", "task_drop_penalty",
+                "task_failure_penalty", "task_success_reward", "task_hop_penalty", "edge_node_seed", "task_seed",
+                "failure_seed", "rl_queue_coeff", "link_seed", "k", "beta"]
+    out["cfg_keys"] = np.asarray(cfg_keys)
+    out["cfg_vals"] = np.asarray([float(getattr(args, k)) for k in cfg_keys], dtype=np.float64)
+    out["cpu_core_list"] = np.asarray(args.cpu_core_list, dtype=np.int64)
+    for k, v in _static_tables(args).items():
+        out["static_" + k] = v
+    from optimal.optimal_agent import OptimalAgent
+    args.n_agents, args.n_actions, args.obs_shape = args.edge_node_num, args.edge_node_num + 1, 9
+    args.state_shape = 9 * args.edge_node_num
+    expert = OptimalAgent(args)
+    names = []
+    for ci, (k, pol, eps) in enumerate(cases):
+        res = _replay(args, k, pol, eps, snap_every=10, pol_seed=4321 + ci, expert=expert)
+        name = "c%02d" % ci
+        names.append("%s:%d:%s:%d" % (name, k, pol, eps))
+        for kk in ("actions", "expert_actions", "avail", "reward", "info", "qlen"):
+            out[name + "_" + kk] = res[kk]
+    out["cases"] = np.asarray(names)
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+
+
 def gen_gae():
     import numpy as np
     import torch as th
@@ -294,7 +347,8 @@ def gen_gae():
 
 
 GROUPS = {"rng": gen_rng, "env10": lambda: gen_env("env10"), "env10d": lambda: gen_env("env10d"),
-          "env40": lambda: gen_env("env40"), "gae": gen_gae}
+          "env40": lambda: gen_env("env40"), "gae": gen_gae, "expert10": lambda: gen_expert("expert10"),
+          "expert40": lambda: gen_expert("expert40")}
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:

@@ -203,3 +203,58 @@ def test_single_env_reference_contract():
         assert set(info) == {"finish_task_number", "success_finish_task_number", "drop_task_number",
                              "failure_task_number", "task_completion_time", "max_hop_dict"}
     env.close()
+
+
+@pytest.mark.parametrize("name", ["expert10", "expert40"])
+def test_expert_policy_golden(name):
+    """ec_expert_policy vs OptimalAgent.get_current_optimal_action recorded from the reference at every step
+    (optimal/optimal_agent.py:102-120,166-375): action replay, expert decision compared bit-for-bit."""
+    th = _th()
+    g = load_golden(name)
+    args = args_from_golden(g)
+    N = args.edge_node_num
+    for case, k, pol, eps in golden_cases(g):
+        env = _make_env(args, 1, k)
+        actions, want = g[case + "_actions"], g[case + "_expert_actions"]
+        for t in range(actions.shape[0]):
+            if t % args.episode_limit == 0:
+                env.reset()
+            _, avail = env.observe()
+            assert np.array_equal(avail[0].cpu().numpy(), g[case + "_avail"][t]), (case, t, "avail")
+            got = env.expert_actions()[0].cpu().numpy()
+            assert np.array_equal(got, want[t]), (name, case, pol, t, got, want[t])
+            reward, _, _ = env.step(th.as_tensor(actions[t], device=env.device).reshape(1, N))
+            assert float(reward[0]) == float(np.float32(g[case + "_reward"][t])), (case, t, "reward")
+        env.close()
+
+
+def test_expert_policy_lockstep_batch(oracle_lib):
+    """Expert-driven rollout of a batch, GPU vs oracle in lock step (half of the envs act on the expert's decision,
+    half on the lowest available action, so that queues fill up and remote scoring is exercised)."""
+    th = _th()
+    from marl_amd import _abi
+    g = load_golden("env10")
+    args = args_from_golden(g)
+    B, base, N = 192, 300, args.edge_node_num
+    env = _make_env(args, B, base)
+    orc = oracle_lib.OracleEnv(_abi.config_from_args(args, hop_hist_len=64), env.tables, B, env_id_base=base, n_threads=4)
+    use_expert = (np.arange(B) % 2 == 0)[:, None]
+    n_remote = 0
+    for t in range(220):
+        if t % args.episode_limit == 0:
+            env.reset()
+            orc.reset()
+        _, avail = env.observe()
+        _, oavail = orc.observe()
+        assert np.array_equal(avail.cpu().numpy(), oavail), (t, "avail")
+        got = env.expert_actions().cpu().numpy()
+        want = orc.expert_policy(oavail)
+        assert np.array_equal(got, want), (t, np.argwhere(got != want)[:5])
+        n_remote += int(((want != np.arange(N)) & (want != N)).sum())
+        acts = np.where(use_expert, want, oavail.argmax(-1))
+        out = orc.step(acts)
+        reward, _, info = env.step(th.as_tensor(acts, device=env.device))
+        assert np.array_equal(reward.cpu().numpy(), out["reward"].astype(np.float32)), (t, "reward")
+        assert np.array_equal(info["counters"].cpu().numpy(), out["counters"]), (t, "counters")
+    assert n_remote > 1000
+    env.close()

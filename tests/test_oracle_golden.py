@@ -91,3 +91,29 @@ def test_gae_matches_reference(oracle_lib):
     for tag in ("a", "b"):
         adv = oracle_lib.gae(g[tag + "_r"], g[tag + "_v"], g[tag + "_nv"], g[tag + "_m"], 0.99, 0.95)
         assert np.array_equal(adv, g[tag + "_adv"][..., 0]), tag
+
+
+@pytest.mark.parametrize("name", ["expert10", "expert40"])
+def test_expert_policy_matches_optimal_agent(oracle_lib, name):
+    """oc_expert_policy vs OptimalAgent.get_current_optimal_action (optimal_agent.py:102-120,166-375) recorded at
+    every step of expert-driven and expert/random-mixed trajectories."""
+    g = load_golden(name)
+    args = args_from_golden(g)
+    tables = build_static_tables(args)
+    cfg = config_from_args(args, hop_hist_len=64)
+    for case, k, pol, eps in golden_cases(g):
+        env = oracle_lib.OracleEnv(cfg, tables, 1, env_id_base=k)
+        actions, want = g[case + "_actions"], g[case + "_expert_actions"]
+        n_remote = 0
+        for t in range(actions.shape[0]):
+            if t % cfg.episode_limit == 0:
+                env.reset()
+            _, avail = env.observe()
+            assert np.array_equal(avail[0], g[case + "_avail"][t]), (case, t, "avail")
+            got = env.expert_policy(avail)[0]
+            assert np.array_equal(got, want[t]), (case, pol, t, got, want[t])
+            n_remote += int(((got != np.arange(cfg.n_nodes)) & (got != cfg.n_nodes)).sum())
+            out = env.step(actions[t])
+            assert out["reward"][0] == g[case + "_reward"][t], (case, t, "reward")
+        assert n_remote > 50  # the fixture exercises the remote-scoring branch
+        env.close()
