@@ -1,0 +1,357 @@
+"""DGAIL learner with the reference's agent interface (rl/policy_gradient_rl/dgail/dgail_agent.py:58-535) on
+device-resident batches of n_threads environments.
+
+What runs where
+  * rollout: `select_actions` = one launch of the fused policy kernel (ec_policy_forward); the expert's decisions come
+    from the env's device state (ec_expert_policy), not from walking Python env objects;
+  * reward evaluation (`_compute_rewards`, :471-518): ec_gail_reward (default, `use_simplified_reward`) or
+    ec_diffusion_reward (both compute_loss passes, D_phi and -log(1 - D_phi)) — no autograd graph is built for rewards;
+  * GAE: ec_gae; discriminator / policy / value updates: torch autograd with the reference's losses.
+
+Batching conventions (the reference's DGAIL runs one environment; everything below reduces to it for n_threads = 1)
+  * expert transitions are per env step, stored in a device FIFO (`ExpertTransitions`);
+  * `_update_policy` keeps the reference's NUMBER of minibatches per epoch: the minibatch holds
+    ppo_batch_size * n_threads rows (64 rows at n_threads = 1, dgail_config.py:16);
+  * with torch.distributed every rank owns a shard of envs; gradients are averaged over ranks with one flat
+    all-reduce per optimiser step, advantage normalisation uses the global mean / std.
+"""
+import os
+
+import numpy as np
+import torch as th
+import torch.nn.functional as F
+from torch.optim import Adam
+
+from marl_amd.buffer.expert_transitions import ExpertTransitions
+from marl_amd.buffer.ppo_expert_buffer import PPOExpertBuffer
+from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import (DiffusionDiscriminator, GAILDiscriminator, PolicyNet,
+                                                                ValueNet)
+from marl_amd.utils import mlp_device
+from marl_amd.utils.action_selectors import greedy_selector, soft_selector
+from marl_amd.utils.advantage_utils import get_gae
+from marl_amd.utils.dist_utils import all_reduce_grads_, broadcast_params_, global_mean, global_mean_std
+
+
+class DGAILAgent:
+    def __init__(self, args):
+        self.args = args
+        self.n_actions = args.n_actions
+        self.n_agents = args.n_agents
+        self.state_shape = getattr(args, "state_shape", args.obs_shape * args.n_agents)
+        self.obs_shape = args.obs_shape
+        self.device = th.device(getattr(args, "ec_force_device", None) or args.device)
+
+        self.state_action_dim = self.obs_shape + self.n_actions
+        self.policy_input_dim = self.obs_shape + self.n_agents
+
+        self.policy = PolicyNet(self.policy_input_dim, self.n_actions, args.hidden_dim).to(self.device)
+        self.value = ValueNet(self.obs_shape, args.hidden_dim).to(self.device)
+        self.discriminator = DiffusionDiscriminator(self.state_action_dim, args.hidden_dim).to(self.device)
+        self.gail_discriminator = GAILDiscriminator(self.state_action_dim, args.hidden_dim).to(self.device)
+        broadcast_params_([self.policy, self.value, self.discriminator, self.gail_discriminator])
+
+        self.policy_optimizer = Adam(self.policy.parameters(), lr=args.policy_lr)
+        self.value_optimizer = Adam(self.value.parameters(), lr=args.value_lr)
+        self.discriminator_optimizer = Adam(self.discriminator.parameters(), lr=args.discriminator_lr)
+        self.gail_discriminator_optimizer = Adam(self.gail_discriminator.parameters(), lr=args.gail_discriminator_lr)
+
+        self.buffer = PPOExpertBuffer(args, device=self.device)
+        self.expert_transitions = ExpertTransitions(args.max_expert_buffer_size, self.n_agents, self.obs_shape,
+                                                    self.device)
+        self.max_expert_buffer_size = args.max_expert_buffer_size
+
+        self.update_count = 0
+        self.training_stats = {}
+        self._bc_pretrain_steps = 700                                      # dgail_agent.py:92-93
+        self._bc_optimizer = Adam(self.policy.parameters(), lr=1e-3)
+        self._disc_update_count = 0
+        self._success_ema = 0.0
+        self._w_factor = 1.0
+        self._target_success = 0.95
+        self._use_simplified_reward = getattr(args, "use_simplified_reward", True)
+        self.bc_loss_weight = getattr(args, "bc_loss_weight", 0.3)
+        self.bc_decay_rate = getattr(args, "bc_decay_rate", 0.995)
+        self.min_bc_weight = getattr(args, "min_bc_weight", 0.05)
+        self.performance_history = []
+        self._eye = th.eye(self.n_agents, device=self.device)
+
+    # ------------------------------------------------------------------ acting
+    def _fused_ok(self):
+        return (self.device.type == "cuda" and self.args.hidden_dim == 64 and self.obs_shape == mlp_device.OBS_DIM
+                and self.n_actions <= 64)
+
+    def _with_ids(self, obs):
+        return th.cat([obs, self._eye.expand(*obs.shape[:-2], -1, -1)], dim=-1)
+
+    @th.no_grad()
+    def select_actions(self, obs, avail_actions, test_mode=False):
+        """dgail_agent.py:114-126: masked policy logits; greedy in test mode, categorical draw otherwise."""
+        obs = obs.to(self.device)
+        avail_actions = avail_actions.to(self.device)
+        if self._fused_ok():
+            lead = obs.shape[:-1]
+            u = None if test_mode else th.rand(obs.numel() // obs.shape[-1], device=self.device)
+            _, _, actions = mlp_device.policy_forward(mlp_device.linear_params(self.policy), obs, self.n_agents,
+                                                      avail_actions, u, want_probs=False)
+            return actions.view(lead)
+        logits = self.policy(self._with_ids(obs))
+        logits[avail_actions == 0] = -1e10
+        return greedy_selector(logits) if test_mode else soft_selector(logits)
+
+    def get_expert_actions(self, env):
+        """dgail_agent.py:128-133: OptimalAgent.get_current_optimal_action for the (batched) env."""
+        return env.expert_actions()
+
+    def store_expert_data(self, obs, actions, select=None):
+        """dgail_agent.py:135-149.  obs [B,N,O], actions [B,N]; select [B] marks the envs that were expert-driven."""
+        self.expert_transitions.append(obs, actions, select)
+
+    # ------------------------------------------------------------------ losses
+    def _compute_bc_loss(self):
+        """dgail_agent.py:151-168: cross entropy on `batch_expert_transitions` random expert transitions."""
+        obs, act = self.expert_transitions.sample_transitions(self.args.batch_expert_transitions)
+        logits = self.policy(self._with_ids(obs).reshape(-1, self.policy_input_dim))
+        return F.nll_loss(F.log_softmax(logits, dim=-1), act.reshape(-1), reduction="mean")
+
+    def _update_bc_weight(self):
+        """dgail_agent.py:170-178"""
+        if len(self.performance_history) < 5:
+            self.bc_loss_weight = max(self.min_bc_weight, self.bc_loss_weight * self.bc_decay_rate)
+            return
+        recent = float(np.mean(self.performance_history[-5:]))
+        if recent < 0.75:
+            self.bc_loss_weight = min(2.0, self.bc_loss_weight * 1.1)
+        else:
+            self.bc_loss_weight = max(self.min_bc_weight, self.bc_loss_weight * self.bc_decay_rate)
+
+    def _prepare_batch(self, obs, actions):
+        """(obs | one-hot action) rows, dgail_agent.py:180-201"""
+        obs_flat = th.as_tensor(obs, dtype=th.float32, device=self.device).reshape(-1, self.obs_shape)
+        actions_flat = th.as_tensor(actions, dtype=th.long, device=self.device).reshape(-1)
+        if obs_flat.shape[0] != actions_flat.shape[0]:
+            raise ValueError("Mismatched number of transitions in obs (%d) and actions (%d)"
+                             % (obs_flat.shape[0], actions_flat.shape[0]))
+        return th.cat([obs_flat, F.one_hot(actions_flat, num_classes=self.n_actions).float()], dim=-1)
+
+    def _expert_sa(self, n_rows):
+        obs, act = self.expert_transitions.sample_rows(n_rows)
+        return self._prepare_batch(obs, act)
+
+    def _d_phi(self, sa):
+        ones = th.ones(sa.size(0), dtype=th.long, device=self.device)
+        lp = self.discriminator.compute_loss(sa, ones)
+        ln = self.discriminator.compute_loss(sa, th.zeros_like(ones))
+        return th.exp(-lp) / (th.exp(-lp) + th.exp(-ln) + 1e-8)
+
+    def _update_discriminator(self, agent_sa):
+        """Diffusion discriminator step, dgail_agent.py:203-243."""
+        if len(self.expert_transitions) < self.args.batch_size_run:
+            return 0.0, 0.0, 0.0
+        prob_expert = self._d_phi(self._expert_sa(agent_sa.size(0)))
+        loss_expert = F.binary_cross_entropy(prob_expert, th.ones_like(prob_expert))
+        prob_agent = self._d_phi(agent_sa)
+        loss_agent = F.binary_cross_entropy(prob_agent, th.zeros_like(prob_agent))
+        loss = loss_expert + loss_agent
+        self.discriminator_optimizer.zero_grad()
+        loss.backward()
+        all_reduce_grads_(list(self.discriminator.parameters()), average=True)
+        self.discriminator_optimizer.step()
+        self._disc_update_count += 1
+        return (float(global_mean(loss.detach().reshape(1))), float(global_mean(prob_expert.detach())),
+                float(global_mean(prob_agent.detach())))
+
+    def _update_gail_discriminator(self, agent_sa):
+        """dgail_agent.py:418-444"""
+        if len(self.expert_transitions) < self.args.batch_size_run:
+            return 0.0
+        prob_expert = self.gail_discriminator(self._expert_sa(agent_sa.size(0)))
+        prob_agent = self.gail_discriminator(agent_sa)
+        loss = -(th.log(prob_expert + 1e-8).mean() + th.log(1 - prob_agent + 1e-8).mean())
+        self.gail_discriminator_optimizer.zero_grad()
+        loss.backward()
+        all_reduce_grads_(list(self.gail_discriminator.parameters()), average=True)
+        self.gail_discriminator_optimizer.step()
+        return float(global_mean(loss.detach().reshape(1)))
+
+    # ------------------------------------------------------------------ rewards (HIP kernels)
+    def _imitation_weight(self, t_env):
+        """scalar multiplier of the base reward, dgail_agent.py:501-513"""
+        if self._use_simplified_reward:
+            return 1.0 - 0.2 * min(1.0, t_env / 80000.0)
+        a = self.args
+        progress = min(1.0, t_env / getattr(a, "w_anneal_tau", 50000))
+        imit = getattr(a, "imit_weight_start", 1.0) * (1 - progress) + getattr(a, "imit_weight_end", 0.1) * progress
+        return imit * self._w_factor * (0.5 + min(1.0, self.update_count / 3000.0) * 0.5)
+
+    @th.no_grad()
+    def _compute_rewards(self, obs, actions, env_r, t_env):
+        """dgail_agent.py:471-518.  -log(1 - D) of the GAIL discriminator (default / after the switch) or of the
+        diffusion discriminator's D_phi, scaled by the annealed weight, plus 0.02 * environment reward."""
+        a = self.args
+        use_gail = a.switch_to_gail_at_step != -1 and t_env >= a.switch_to_gail_at_step
+        weight = self._imitation_weight(t_env)
+        obs_flat = obs.reshape(-1, self.obs_shape)
+        act_flat = actions.reshape(-1)
+        env_flat = env_r.to(self.device).reshape(-1)
+        if not (self.device.type == "cuda" and a.hidden_dim == 64):
+            return self._compute_rewards_torch(obs, actions, env_r, use_gail, weight)
+        if use_gail or self._use_simplified_reward:
+            final, _ = mlp_device.gail_reward(mlp_device.linear_params(self.gail_discriminator), obs_flat, act_flat,
+                                              self.n_actions, weight=weight, env_reward=env_flat, env_coef=0.02)
+        else:
+            rows = obs_flat.shape[0]
+            d = self.discriminator
+            # the (t, noise) draws of the two compute_loss calls (dgail_network.py:90-91)
+            t_e = th.randint(0, 2, (rows,), device=self.device, dtype=th.uint8)
+            t_a = th.randint(0, 2, (rows,), device=self.device, dtype=th.uint8)
+            n_e = th.randn(rows, self.state_action_dim, device=self.device)
+            n_a = th.randn(rows, self.state_action_dim, device=self.device)
+            _, _, _, base = mlp_device.diffusion_reward(mlp_device.linear_params(d.mlp), d.time_embed.weight,
+                                                        d.cond_embed.weight, obs_flat, act_flat, self.n_actions, t_e,
+                                                        n_e, t_a, n_a, r1_lambda=d.R1_LAMBDA)
+            final = base * weight + 0.02 * env_flat
+        return final.reshape(obs.shape[0], obs.shape[1], obs.shape[2], 1)
+
+    def _compute_rewards_torch(self, obs, actions, env_r, use_gail, weight):
+        """The same arithmetic in torch ops, for devices / shapes the HIP entry points do not cover."""
+        sa = self._prepare_batch(obs, actions)
+        if use_gail or self._use_simplified_reward:
+            p = self.gail_discriminator(sa).clamp(1e-8, 1 - 1e-8)
+            base = -th.log(1.0 - p).squeeze(-1)
+        else:
+            with th.enable_grad():
+                base = -th.log(1.0 - self._d_phi(sa) + 1e-8).detach()
+        final = base * weight + 0.02 * env_r.to(self.device).reshape(-1)
+        return final.reshape(obs.shape[0], obs.shape[1], obs.shape[2], 1)
+
+    def _drail_or_gail_reward(self, state_action, t_env):
+        """dgail_agent.py:446-469 (log-ratio form; not used by train(), kept for interface parity)"""
+        a = self.args
+        if a.switch_to_gail_at_step != -1 and t_env >= a.switch_to_gail_at_step:
+            p = self.gail_discriminator(state_action).clamp(1e-8, 1 - 1e-8)
+            return (-th.log(1.0 - p).squeeze(-1)).detach()
+        with th.enable_grad():
+            d_phi = self._d_phi(state_action)
+        return (-(th.log(d_phi + 1e-8) - th.log(1.0 - d_phi + 1e-8))).detach()
+
+    # ------------------------------------------------------------------ policy / value update
+    def _update_policy(self, batch):
+        """Minibatch PPO with the joint loss policy - c_H*H + c_V*value + w_bc*BC, dgail_agent.py:245-333."""
+        a = self.args
+        obs = batch["obs"]
+        actions = batch["actions"]
+        masks = batch["masks"]
+        next_obs = batch["next_obs"]
+        rewards = batch["rewards"]
+        B, T, N = obs.shape[0], obs.shape[1], obs.shape[2]
+        policy_input = self._with_ids(obs).reshape(-1, self.policy_input_dim)
+        with th.no_grad():
+            values = self.value(obs.reshape(-1, self.obs_shape)).reshape(B, T, N, 1)
+            next_values = self.value(next_obs.reshape(-1, self.obs_shape)).reshape(B, T, N, 1)
+            advantages = get_gae(a, rewards, values, next_values, masks)
+            returns = advantages + values
+            mean, std = global_mean_std(advantages)
+            advantages = (advantages - mean) / (std + 1e-8)
+            log_probs_old = th.distributions.Categorical(logits=self.policy(policy_input)).log_prob(actions.reshape(-1))
+        act_f = actions.reshape(-1)
+        ret_f = returns.reshape(-1, 1)
+        adv_f = advantages.reshape(-1)
+        rows = act_f.shape[0]
+        mb = max(1, int(a.ppo_batch_size) * int(getattr(a, "n_threads", 1)))
+        n_mb = (rows + mb - 1) // mb
+        totals = th.zeros(3, device=self.device)
+        for _ in range(a.ppo_epochs):
+            perm = th.randperm(rows, device=self.device)
+            for i in range(n_mb):
+                idx = perm[i * mb:(i + 1) * mb]
+                x = policy_input[idx]
+                dist_new = th.distributions.Categorical(logits=self.policy(x))
+                log_probs_new = dist_new.log_prob(act_f[idx])
+                entropy = dist_new.entropy().mean()
+                ratio = th.exp(log_probs_new - log_probs_old[idx])
+                adv_b = adv_f[idx]
+                policy_loss = -th.min(ratio * adv_b, th.clamp(ratio, 1.0 - a.clip_param, 1.0 + a.clip_param) * adv_b).mean()
+                value_loss = ((self.value(x[:, :self.obs_shape]) - ret_f[idx]) ** 2).mean()
+                bc_loss = self._compute_bc_loss()
+                loss = (policy_loss - a.entropy_coef * entropy + a.value_loss_coef * value_loss
+                        + self.bc_loss_weight * bc_loss)
+                self.policy_optimizer.zero_grad()
+                self.value_optimizer.zero_grad()
+                loss.backward()
+                all_reduce_grads_(list(self.policy.parameters()) + list(self.value.parameters()), average=True)
+                th.nn.utils.clip_grad_norm_(self.policy.parameters(), a.grad_norm_clip)
+                th.nn.utils.clip_grad_norm_(self.value.parameters(), a.grad_norm_clip)
+                self.policy_optimizer.step()
+                self.value_optimizer.step()
+                totals += th.stack([policy_loss.detach(), value_loss.detach(), entropy.detach()])
+        totals = (totals / (a.ppo_epochs * n_mb)).tolist()
+        return {"policy_loss": totals[0], "value_loss": totals[1], "entropy": totals[2]}
+
+    def _bc_pretrain(self):
+        """dgail_agent.py:520-534: `_bc_pretrain_steps` Adam(1e-3) steps, one random expert transition each."""
+        for _ in range(self._bc_pretrain_steps):
+            obs_e, act_e = self.expert_transitions.sample_transitions(1)
+            logits = self.policy(self._with_ids(obs_e).reshape(-1, self.policy_input_dim))
+            loss = F.cross_entropy(logits, act_e.reshape(-1))
+            self._bc_optimizer.zero_grad()
+            loss.backward()
+            all_reduce_grads_(list(self.policy.parameters()), average=True)
+            self._bc_optimizer.step()
+
+    def train(self, t_env):
+        """One training iteration on the rollout in the buffer, dgail_agent.py:335-381."""
+        if len(self.expert_transitions) < self.args.batch_size_run:
+            print("Insufficient expert data (%d/%d), skip this training." % (len(self.expert_transitions),
+                                                                            self.args.batch_size_run))
+            return None
+        if self._bc_pretrain_steps > 0:
+            self._bc_pretrain()
+            self._bc_pretrain_steps = 0
+        obs, avail_actions, actions, env_rewards, masks, next_obs = self.buffer.sample()
+        batch = {"obs": obs, "avail_actions": avail_actions, "actions": actions, "rewards": env_rewards, "masks": masks,
+                 "next_obs": next_obs}
+        agent_sa = self._prepare_batch(obs, actions)
+        disc_loss, prob_expert, prob_agent = self._update_discriminator(agent_sa)
+        gail_disc_loss = self._update_gail_discriminator(agent_sa)
+        del agent_sa
+        imitation_rewards = self._compute_rewards(obs, actions, env_rewards, t_env)
+        batch["rewards"] = imitation_rewards
+        policy_stats = self._update_policy(batch)
+        self.update_count += 1
+        self._update_bc_weight()
+        return {"discriminator_loss": disc_loss, "gail_discriminator_loss": gail_disc_loss, "prob_expert": prob_expert,
+                "prob_agent": prob_agent, "avg_imitation_reward": float(global_mean(imitation_rewards)), **policy_stats}
+
+    def update_performance_monitoring(self, success_rate):
+        """dgail_agent.py:383-401"""
+        self._success_ema = 0.9 * self._success_ema + 0.1 * success_rate
+        if self._use_simplified_reward:
+            if self._success_ema < 0.75:
+                self._w_factor = min(self._w_factor * 1.02, 1.5)
+            elif self._success_ema > 0.99:
+                self._w_factor = max(self._w_factor * 0.998, 0.9)
+        else:
+            if self._success_ema < self._target_success - 0.05:
+                self._w_factor = min(self._w_factor * 1.05, 2.0)
+            elif self._success_ema > self._target_success + 0.05:
+                self._w_factor = max(self._w_factor * 0.999, 0.9)
+        self.training_stats["w_factor"] = self._w_factor
+        self.performance_history.append(success_rate)
+        if len(self.performance_history) > 30:
+            self.performance_history.pop(0)
+
+    # ------------------------------------------------------------------ checkpoints (reference file names)
+    def save_models(self, path):
+        os.makedirs(path, exist_ok=True)
+        th.save(self.policy.state_dict(), "%s/policy_net.pth" % path)
+        th.save(self.value.state_dict(), "%s/value_net.pth" % path)
+        th.save(self.discriminator.state_dict(), "%s/discriminator.pth" % path)
+
+    def load_models(self, path):
+        kw = dict(map_location=self.device, weights_only=True)
+        self.policy.load_state_dict(th.load("%s/policy_net.pth" % path, **kw))
+        self.value.load_state_dict(th.load("%s/value_net.pth" % path, **kw))
+        self.discriminator.load_state_dict(th.load("%s/discriminator.pth" % path, **kw))
+
+    def reset_training_stats(self):
+        self.training_stats = {}

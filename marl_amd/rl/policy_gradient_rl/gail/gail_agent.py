@@ -1,0 +1,219 @@
+"""GAIL learner with the reference's agent interface (rl/policy_gradient_rl/gail/gail_agent.py:16-265) on
+device-resident batches of n_threads environments.
+
+Per training call (:128-231): one discriminator step (BCE-with-logits, rollout rows labelled 1, 64 sampled expert
+transitions labelled 0), rewards  -log sigmoid(x) + log sigmoid(-x)  from the updated discriminator (still in train
+mode: batch-norm batch statistics and dropout are active, as in the reference), then PPO with the reference's
+normalisation constants (1e-8), the clipped surrogate + entropy, and a behaviour-cloning term whose weight follows
+the success-rate schedule of :118-126.  Acting uses the fused policy kernel; GAE the HIP scan.  Data parallel as
+PPOAgent (flat gradient all-reduce, global normalisation statistics); batch-norm statistics stay per rank.
+"""
+import os
+
+import numpy as np
+import torch as th
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.distributions import Categorical
+from torch.optim import Adam
+
+from marl_amd.buffer.expert_transitions import ExpertTransitions
+from marl_amd.buffer.ppo_expert_buffer import PPOExpertBuffer
+from marl_amd.rl.policy_gradient_rl.gail.gail_network import Actor, Critic, Discriminator
+from marl_amd.utils import mlp_device
+from marl_amd.utils.action_selectors import greedy_selector, soft_selector
+from marl_amd.utils.advantage_utils import get_gae
+from marl_amd.utils.dist_utils import (all_reduce_grads_, all_reduce_sum_, broadcast_params_, global_mean_std,
+                                       world_size)
+
+
+class GAILAgent:
+    def __init__(self, args):
+        self.device = th.device(getattr(args, "ec_force_device", None) or ("cuda" if th.cuda.is_available() else "cpu"))
+        self.args = args
+        self.actor = Actor(args).to(self.device)
+        self.critic = Critic(args).to(self.device)
+        self.discriminator = Discriminator(args).to(self.device)
+        broadcast_params_([self.actor, self.critic, self.discriminator])
+        self.actor_optimizer = Adam(params=self.actor.parameters(), lr=args.lr)
+        self.critic_optimizer = Adam(params=self.critic.parameters(), lr=args.lr)
+        self.discriminator_optimizer = Adam(params=self.discriminator.parameters(), lr=args.lr)
+        self.buffer = PPOExpertBuffer(args, device=self.device)
+        self.bc_loss_weight = getattr(args, "bc_loss_weight", 1.0)
+        self.bc_decay_rate = getattr(args, "bc_decay_rate", 0.99)
+        self.min_bc_weight = getattr(args, "min_bc_weight", 0.1)
+        self.expert_transitions = ExpertTransitions(args.max_expert_buffer_size, args.n_agents, args.obs_shape,
+                                                    self.device)
+        self.max_expert_buffer_size = args.max_expert_buffer_size
+        self.update_count = 0
+        self.performance_history = []
+        self._eye = th.eye(args.n_agents, device=self.device)
+        self.last_losses = {}
+
+    # ------------------------------------------------------------------ acting
+    def _with_ids(self, obs):
+        return th.cat([obs, self._eye.expand(*obs.shape[:-2], -1, -1)], dim=-1)
+
+    def _fused_ok(self):
+        a = self.args
+        return (self.device.type == "cuda" and getattr(a, "activate_fun", "relu") == "relu" and a.hidden_dim == 64
+                and a.obs_shape == mlp_device.OBS_DIM and a.n_actions <= 64)
+
+    @th.no_grad()
+    def select_actions(self, obs, avail_actions, test_mode=False):
+        """gail_agent.py:46-59"""
+        obs = obs.to(self.device)
+        avail_actions = avail_actions.to(self.device)
+        if self._fused_ok():
+            lead = obs.shape[:-1]
+            u = None if test_mode else th.rand(obs.numel() // obs.shape[-1], device=self.device)
+            _, _, actions = mlp_device.policy_forward(mlp_device.linear_params(self.actor), obs, self.args.n_agents,
+                                                      avail_actions, u, want_probs=False)
+            return actions.view(lead)
+        actor_outs = self.actor(self._with_ids(obs))
+        actor_outs[avail_actions == 0] = -1e10
+        return greedy_selector(actor_outs) if test_mode else soft_selector(actor_outs)
+
+    def get_expert_actions(self, env):
+        """gail_agent.py:61-66: the expert's decision for every env of the batch (ec_expert_policy)."""
+        return env.expert_actions()
+
+    def get_expert_ratio(self, t_env):
+        """gail_agent.py:68-75"""
+        a = self.args
+        if t_env < a.bc_guidance_steps:
+            return 1.0
+        if t_env < a.expert_guidance_steps:
+            progress = (t_env - a.bc_guidance_steps) / (a.expert_guidance_steps - a.bc_guidance_steps)
+            return max(0.2, 0.9 * (1 - progress))
+        return 0.2
+
+    def store_expert_data(self, obs, actions, select=None):
+        """gail_agent.py:77-83"""
+        self.expert_transitions.append(obs, actions, select)
+
+    # ------------------------------------------------------------------ losses
+    def compute_bc_loss(self, obs=None, avail_actions=None, actions=None):
+        """gail_agent.py:85-107: NLL of the expert's actions on 64 sampled expert transitions (unmasked logits)."""
+        if len(self.expert_transitions) == 0:
+            return th.tensor(0.0, device=self.device)
+        e_obs, e_act = self.expert_transitions.sample_transitions(64)
+        log_probs = F.log_softmax(self.actor(self._with_ids(e_obs)), dim=-1)
+        return F.nll_loss(log_probs.view(-1, self.args.n_actions), e_act.view(-1), reduction="mean")
+
+    def evaluate_actions(self, inputs, avail_actions, actions):
+        """gail_agent.py:109-116"""
+        actor_outs = self.actor(inputs).masked_fill(avail_actions == 0, -1e10)
+        dist_ = Categorical(F.softmax(actor_outs, dim=-1))
+        return dist_.log_prob(actions.squeeze(-1)).unsqueeze(-1), dist_.entropy().unsqueeze(-1)
+
+    def update_bc_weight(self):
+        """gail_agent.py:118-126"""
+        if len(self.performance_history) >= 5 and float(np.mean(self.performance_history[-5:])) < 0.7:
+            self.bc_loss_weight = min(2.0, self.bc_loss_weight * 1.1)
+        else:
+            self.bc_loss_weight = max(self.min_bc_weight, self.bc_loss_weight * self.bc_decay_rate)
+
+    def _discriminator_step(self, obs_id, actions):
+        """gail_agent.py:131-172: returns the GAIL rewards [B,T,N,1] of the rollout."""
+        a = self.args
+        B, T, N = obs_id.shape[0], obs_id.shape[1], obs_id.shape[2]
+        onehot = F.one_hot(actions.squeeze(-1), num_classes=a.n_actions).float()
+        e_obs, e_act = self.expert_transitions.sample_transitions(64)
+        expert_logits = self.discriminator(self._with_ids(e_obs), F.one_hot(e_act, num_classes=a.n_actions).float())
+        flat_obs, flat_act = obs_id.reshape(-1, obs_id.size(-1)), onehot.reshape(-1, onehot.size(-1))
+        agent_logits = self.discriminator(flat_obs, flat_act)
+        bce = nn.BCEWithLogitsLoss()
+        loss = bce(agent_logits.reshape(-1, 1), th.ones_like(agent_logits.reshape(-1, 1))) + \
+            bce(expert_logits, th.zeros_like(expert_logits))
+        self.discriminator_optimizer.zero_grad()
+        loss.backward()
+        all_reduce_grads_(list(self.discriminator.parameters()), average=True)
+        if a.use_grad_clip:
+            th.nn.utils.clip_grad_norm_(self.discriminator.parameters(), a.grad_norm_clip)
+        self.discriminator_optimizer.step()
+        with th.no_grad():
+            x = self.discriminator(flat_obs, flat_act).reshape(B, T, N, 1)
+            rewards = -F.logsigmoid(x) + F.logsigmoid(-x)
+        self.last_losses["discriminator_loss"] = loss.detach()
+        return rewards
+
+    def train(self):
+        a = self.args
+        obs, avail_actions, actions, rewards, masks, next_obs = self.buffer.sample()
+        obs_id = self._with_ids(obs)
+        next_obs_id = self._with_ids(next_obs)
+        if len(self.expert_transitions) >= 10:
+            rewards = self._discriminator_step(obs_id, actions)
+        if a.normalize_rewards:
+            mean, std = global_mean_std(rewards)
+            rewards = (rewards - mean) / (std + 1e-8)
+        with th.no_grad():
+            old_log_pi_taken, _ = self.evaluate_actions(obs_id, avail_actions, actions)
+            old_v = self.critic(obs_id)
+            old_next_v = self.critic(next_obs_id)
+            advantages = get_gae(a, rewards, old_v, old_next_v, masks)
+            if a.normalize_advantages:
+                mean, std = global_mean_std(advantages)
+                advantages = (advantages - mean) / (std + 1e-8)
+            targets = advantages + old_v
+            denom = all_reduce_sum_(masks.sum().reshape(1).clone())
+        self.update_bc_weight()
+        for _ in range(a.epochs):
+            log_pi_taken, entropy = self.evaluate_actions(obs_id, avail_actions, actions)
+            v = self.critic(obs_id)
+            critic_loss = (((v - targets) * masks) ** 2).sum() / denom
+            self.critic_optimizer.zero_grad()
+            critic_loss.backward()
+            all_reduce_grads_(list(self.critic.parameters()))
+            if a.use_grad_clip:
+                th.nn.utils.clip_grad_norm_(self.critic.parameters(), a.grad_norm_clip)
+            self.critic_optimizer.step()
+
+            ratios = th.exp(log_pi_taken - old_log_pi_taken)
+            surr1 = ratios * advantages
+            surr2 = th.clamp(ratios, 1 - a.eps_clip, 1 + a.eps_clip) * advantages
+            objective = th.min(surr1, surr2)
+            if a.use_entropy:
+                objective = objective + a.entropy_coef * entropy
+            ppo_loss = -(objective * masks).sum() / denom
+            # the BC term is a mean over this rank's sample: weight it 1/world so that the summed gradient is the mean
+            total_actor_loss = ppo_loss + self.bc_loss_weight * self.compute_bc_loss() / world_size()
+            self.actor_optimizer.zero_grad()
+            total_actor_loss.backward()
+            all_reduce_grads_(list(self.actor.parameters()))
+            if a.use_grad_clip:
+                th.nn.utils.clip_grad_norm_(self.actor.parameters(), a.grad_norm_clip)
+            self.actor_optimizer.step()
+        self.update_count += 1
+        self.last_losses.update({"critic_loss": critic_loss.detach(), "actor_loss": ppo_loss.detach()})
+        if self.update_count % 100 == 0:
+            print("Update %d: BC weight = %.4f, expert data size = %d" % (self.update_count, self.bc_loss_weight,
+                                                                         len(self.expert_transitions)))
+
+    def update_performance_monitoring(self, success_rate):
+        """gail_agent.py:233-236"""
+        self.performance_history.append(success_rate)
+        if len(self.performance_history) > 20:
+            self.performance_history.pop(0)
+
+    # ------------------------------------------------------------------ checkpoints (reference file names)
+    def save_models(self, path):
+        os.makedirs(path, exist_ok=True)
+        th.save(self.actor.state_dict(), "{}/actor.th".format(path))
+        th.save(self.critic.state_dict(), "{}/critic.th".format(path))
+        th.save(self.discriminator.state_dict(), "{}/discriminator.th".format(path))
+        if len(self.expert_transitions):
+            th.save(self.expert_transitions.state_dict(), "{}/expert_data.th".format(path))
+
+    def load_models(self, path):
+        kw = dict(map_location=self.device, weights_only=True)
+        self.actor.load_state_dict(th.load("{}/actor.th".format(path), **kw))
+        self.critic.load_state_dict(th.load("{}/critic.th".format(path), **kw))
+        if os.path.exists("{}/discriminator.th".format(path)):
+            self.discriminator.load_state_dict(th.load("{}/discriminator.th".format(path), **kw))
+        if os.path.exists("{}/expert_data.th".format(path)):
+            self.expert_transitions.load_state_dict(th.load("{}/expert_data.th".format(path), **kw))
+
+    def load_offline_models(self, path):
+        self.load_models(path)

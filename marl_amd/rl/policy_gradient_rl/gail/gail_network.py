@@ -1,0 +1,71 @@
+"""Networks of the reference's GAIL agent (rl/policy_gradient_rl/gail/gail_network.py:7-132); parameter names match
+so that its actor.th / critic.th / discriminator.th checkpoints load unchanged."""
+import torch as th
+import torch.nn as nn
+import torch.nn.functional as F
+
+_ACT = {"relu": F.relu, "tanh": th.tanh, "leaky_relu": F.leaky_relu}
+
+
+def _act(args, allow):
+    name = getattr(args, "activate_fun", "relu")
+    return _ACT[name] if name in allow else F.relu
+
+
+class _ActorCritic(nn.Module):
+    def __init__(self, args, n_out):
+        super().__init__()
+        self.args = args
+        self.fc1 = nn.Linear(args.obs_shape + args.n_agents, args.hidden_dim)
+        self.fc2 = nn.Linear(args.hidden_dim, args.hidden_dim)
+        self.fc3 = nn.Linear(args.hidden_dim, n_out)
+        self.activate_func = _act(args, ("relu", "tanh"))
+
+    def forward(self, obs):
+        return self.fc3(self.activate_func(self.fc2(self.activate_func(self.fc1(obs)))))
+
+
+class Actor(_ActorCritic):
+    """gail_network.py:7-30"""
+
+    def __init__(self, args):
+        super().__init__(args, args.n_actions)
+
+
+class Critic(_ActorCritic):
+    """gail_network.py:33-56"""
+
+    def __init__(self, args):
+        super().__init__(args, 1)
+
+
+class Discriminator(nn.Module):
+    """gail_network.py:59-132: (obs | agent id | one-hot action) -> 2H -> H -> H/2 -> 1 logit, each hidden layer
+    Linear -> BatchNorm (skipped for a single row) -> activation -> Dropout; Xavier-uniform weights, zero biases."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        h = args.hidden_dim
+        widths = (args.obs_shape + args.n_agents + args.n_actions, h * 2, h, h // 2)
+        for i, p in enumerate((0.3, 0.3, 0.2), start=1):
+            setattr(self, "fc%d" % i, nn.Linear(widths[i - 1], widths[i]))
+            setattr(self, "bn%d" % i, nn.BatchNorm1d(widths[i]))
+            setattr(self, "dropout%d" % i, nn.Dropout(p))
+        self.fc4 = nn.Linear(widths[3], 1)
+        self.activate_func = _act(args, ("relu", "tanh", "leaky_relu"))
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, obs, actions):
+        lead = obs.shape[:-1]
+        x = th.cat([obs.reshape(-1, obs.shape[-1]), actions.reshape(-1, actions.shape[-1])], dim=-1)
+        for i in (1, 2, 3):
+            x = getattr(self, "fc%d" % i)(x)
+            if x.shape[0] > 1:
+                x = getattr(self, "bn%d" % i)(x)
+            x = getattr(self, "dropout%d" % i)(self.activate_func(x))
+        x = self.fc4(x)
+        return x.view(*lead, 1) if len(lead) > 1 else x

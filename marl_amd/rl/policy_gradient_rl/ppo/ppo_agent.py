@@ -24,41 +24,7 @@ from marl_amd.utils.advantage_utils import get_gae
 from marl_amd.utils import mlp_device
 
 
-def _dist_on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-
-
-def all_reduce_sum_(t):
-    if _dist_on():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t
-
-
-def all_reduce_grads_(params):
-    """Sum gradients over ranks with a single flat all-reduce."""
-    if not _dist_on():
-        return
-    grads = [p.grad for p in params if p.grad is not None]
-    flat = th.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
-        off += n
-
-
-def global_mean_std(x, eps_count=1):
-    """mean and UNBIASED std over all ranks' elements, as tensor.mean()/tensor.std() of the concatenation."""
-    n = th.tensor([float(x.numel())], device=x.device, dtype=th.float64)
-    s = x.double().sum().reshape(1)
-    all_reduce_sum_(n)
-    all_reduce_sum_(s)
-    mean = s / n
-    ss = ((x.double() - mean) ** 2).sum().reshape(1)
-    all_reduce_sum_(ss)
-    std = th.sqrt(ss / (n - 1))
-    return mean.float(), std.float()
+from marl_amd.utils.dist_utils import all_reduce_grads_, all_reduce_sum_, dist_on as _dist_on, global_mean_std  # noqa: E402,F401
 
 
 class PPOAgent:

@@ -1,0 +1,125 @@
+"""`DGAILRunner` on the batched HIP environment.
+
+Same contract as the reference's runners/dgail_runner.py:5-156 — `DGAILRunner(args, agent)`,
+`.run(test_mode) -> ep_info`, `.t_env`, `.close_env()` — for args.n_threads environments in lock step (the reference
+runs one).  Per step and per env a coin with the scheduled expert ratio (:30-38,46) decides whether the env executes the
+expert's action (ec_expert_policy on the device state) or the agent's; the agent's action is what the PPO buffer
+stores either way (:81), and expert-driven envs append (obs, expert action) to the agent's expert store (:93-94).
+`t_env` counts env steps summed over the batch, as ParallelRunner does (parallel_episode_runner.py:103-104).
+"""
+import torch as th
+import torch.distributed as dist
+
+from marl_amd.envs.env_register import env_register
+from marl_amd.utils.dist_utils import dist_on
+
+
+class DGAILRunner:
+    def __init__(self, args, agent):
+        self.args = args
+        self.agent = agent
+        self.env = env_register["edge_computing_batched"](args, n_envs=args.n_threads,
+                                                          env_id_base=getattr(args, "ec_env_id_base", 0))
+        self.t_env = 0
+        self.episode_count = 0
+        self.bc_guidance_steps = getattr(args, "bc_guidance_steps", 2_000)
+        self.expert_guidance_steps = getattr(args, "expert_guidance_steps", 6_000)
+        B, N = args.n_threads, args.n_agents
+        dev = self.env.device
+        self._obs = th.empty(B, N, args.obs_shape, dtype=th.float, device=dev)
+        self._avail = th.empty(B, N, args.n_actions, dtype=th.int, device=dev)
+        self._totals = th.zeros(6, dtype=th.float64, device=dev)
+        self.expert_steps = 0  # expert-driven env steps of the last episode
+
+    def _expert_ratio(self):
+        """dgail_runner.py:30-38"""
+        if self.t_env < self.bc_guidance_steps:
+            return 1.0
+        if self.t_env < self.expert_guidance_steps:
+            progress = (self.t_env - self.bc_guidance_steps) / (self.expert_guidance_steps - self.bc_guidance_steps)
+            return max(0.2, 0.9 * (1 - progress))
+        return 0.2
+
+    def _use_expert(self, test_mode):
+        """bool [B]: which envs act on the expert this step (dgail_runner.py:46)"""
+        B = self.args.n_threads
+        if test_mode:
+            return None
+        return th.rand(B, device=self.env.device) < self._expert_ratio()
+
+    def run(self, test_mode=False):
+        args, env = self.args, self.env
+        B, N = args.n_threads, args.n_agents
+        self.agent.buffer.reset()
+        env.reset()
+        env.observe()
+        self._totals.zero_()
+        n_expert = th.zeros((), dtype=th.int64, device=env.device)
+        steps = 0
+        for t in range(args.episode_limit):
+            self._obs.copy_(env.obs)
+            self._avail.copy_(env.avail)
+            use_expert = self._use_expert(test_mode)
+            agent_actions = self.agent.select_actions(self._obs, self._avail, test_mode)
+            if use_expert is not None:
+                expert_actions = self.agent.get_expert_actions(env)
+                exec_actions = th.where(use_expert.unsqueeze(-1), expert_actions, agent_actions)
+                n_expert += use_expert.sum()
+            else:
+                exec_actions = agent_actions
+            reward, terminated, info = env.step(exec_actions, want_hops=(t == args.episode_limit - 1))
+            steps += 1
+            self._totals[0] += reward.double().sum()
+            self._totals[1] += info["task_completion_time"].double().sum()
+            self._totals[2:6] += info["counters"].double().sum(0)
+            if not test_mode:
+                self.t_env += B
+                rewards = reward.view(B, 1, 1).expand(B, N, 1)
+                masks = (1 - terminated.float()).view(B, 1, 1).expand(B, N, 1)
+                self.agent.buffer.insert(self._obs, self._avail, agent_actions.unsqueeze(-1), rewards, masks, env.obs)
+                self.agent.store_expert_data(self._obs, expert_actions, use_expert)
+        env.check_status()
+        totals = self._totals.clone()
+        n_envs = th.tensor([float(B)], dtype=th.float64, device=totals.device)
+        hops = env.hop_hist.double().sum(0)
+        if dist_on():
+            dist.all_reduce(totals)
+            dist.all_reduce(n_envs)
+            dist.all_reduce(hops)
+        ret, ctime, fin, succ, drop, fail = totals.tolist()
+        self.expert_steps = int(n_expert.item())
+        finish_cnt = max(fin, 1)
+        success_base = max(succ + drop, 1)
+        ep_info = {
+            "episode_return": ret / n_envs.item(),        # per env, :116
+            "success_rate": succ / finish_cnt,
+            "drop_rate": drop / finish_cnt,
+            "failure_rate": fail / finish_cnt,
+            "task_completion_time": ctime / success_base,
+            "max_hop_dict": {h: int(c) for h, c in enumerate(hops.tolist()) if c},
+            "episode_steps": steps,
+            "expert_buffer_size": len(self.agent.expert_transitions),
+        }
+        if not test_mode and ep_info["expert_buffer_size"] > args.batch_size_run:   # :127-131
+            train_stats = self.agent.train(self.t_env)
+            if train_stats:
+                ep_info.update(train_stats)
+            self.agent.update_performance_monitoring(ep_info["success_rate"])
+        self.episode_count += 1
+        if not test_mode and self.episode_count % 10 == 0:
+            self._print_detailed_stats(ep_info)
+        return ep_info
+
+    def _print_detailed_stats(self, info):
+        if dist_on() and dist.get_rank() != 0:
+            return
+        print("\n--- Episode %d | Env Steps %d ---" % (self.episode_count, self.t_env))
+        print("  success rate: %.4f | Episode return: %.2f" % (info.get("success_rate", 0), info.get("episode_return", 0)))
+        print("  expert buffer size: %d" % info.get("expert_buffer_size", 0))
+        print("  loss of discriminator: %.4f | discriminator output -> expert: %.4f, agent: %.4f"
+              % (info.get("discriminator_loss", -1), info.get("prob_expert", -1), info.get("prob_agent", -1)))
+        print("  imitation_reward: %.4f" % info.get("avg_imitation_reward", 0))
+        print("-" * 50)
+
+    def close_env(self):
+        self.env.close()

@@ -1,0 +1,79 @@
+"""`GAILRunner` on the batched HIP environment: the reference's runners/gail_runner.py:5-116 for args.n_threads
+environments in lock step.  While `t_expert < expert_guidance_steps` each env flips a coin with the agent's scheduled
+expert ratio (:32-34) and executes the expert's action (ec_expert_policy) or the agent's; the PPO buffer always stores
+an action sampled from the agent (:73-77), expert-driven envs also feed the expert store (:97-98); every training
+episode ends with `agent.update_performance_monitoring` and `agent.train()` (:109-111)."""
+import torch as th
+import torch.distributed as dist
+
+from marl_amd.envs.env_register import env_register
+from marl_amd.utils.dist_utils import dist_on
+
+
+class GAILRunner:
+    def __init__(self, args, agent):
+        self.args = args
+        self.agent = agent
+        self.env = env_register["edge_computing_batched"](args, n_envs=args.n_threads,
+                                                          env_id_base=getattr(args, "ec_env_id_base", 0))
+        self.t_env = 0
+        B, N = args.n_threads, args.n_agents
+        dev = self.env.device
+        self._obs = th.empty(B, N, args.obs_shape, dtype=th.float, device=dev)
+        self._avail = th.empty(B, N, args.n_actions, dtype=th.int, device=dev)
+        self._totals = th.zeros(6, dtype=th.float64, device=dev)
+
+    def run(self, test_mode=False, t_expert=0):
+        args, env = self.args, self.env
+        B, N = args.n_threads, args.n_agents
+        self.agent.buffer.reset()
+        env.reset()
+        env.observe()
+        self._totals.zero_()
+        guided = (not test_mode) and t_expert < args.expert_guidance_steps
+        for t in range(args.episode_limit):
+            self._obs.copy_(env.obs)
+            self._avail.copy_(env.avail)
+            agent_actions = self.agent.select_actions(self._obs, self._avail, test_mode)
+            use_expert = None
+            if guided:
+                use_expert = th.rand(B, device=env.device) < self.agent.get_expert_ratio(t_expert)
+                expert_actions = self.agent.get_expert_actions(env)
+                exec_actions = th.where(use_expert.unsqueeze(-1), expert_actions, agent_actions)
+            else:
+                exec_actions = agent_actions
+            reward, terminated, info = env.step(exec_actions, want_hops=(t == args.episode_limit - 1))
+            self._totals[0] += reward.double().sum()
+            self._totals[1] += info["task_completion_time"].double().sum()
+            self._totals[2:6] += info["counters"].double().sum(0)
+            if not test_mode:
+                self.t_env += B
+                rewards = reward.view(B, 1, 1).expand(B, N, 1)
+                masks = (1 - terminated.float()).view(B, 1, 1).expand(B, N, 1)
+                self.agent.buffer.insert(self._obs, self._avail, agent_actions.unsqueeze(-1), rewards, masks, env.obs)
+                if use_expert is not None:
+                    self.agent.store_expert_data(self._obs, expert_actions, use_expert)
+        env.check_status()
+        totals = self._totals.clone()
+        n_envs = th.tensor([float(B)], dtype=th.float64, device=totals.device)
+        hops = env.hop_hist.double().sum(0)
+        if dist_on():
+            dist.all_reduce(totals)
+            dist.all_reduce(n_envs)
+            dist.all_reduce(hops)
+        ret, ctime, fin, succ, drop, fail = totals.tolist()
+        episode_info = {
+            "episode_return": ret / n_envs.item(),
+            "success_rate": succ / max(fin, 1),
+            "drop_rate": drop / max(fin, 1),
+            "failure_rate": fail / max(fin, 1),
+            "task_completion_time": ctime / max(succ + drop, 1),
+            "max_hop_dict": {h: int(c) for h, c in enumerate(hops.tolist()) if c},
+        }
+        if not test_mode:
+            self.agent.update_performance_monitoring(episode_info["success_rate"])
+            self.agent.train()
+        return episode_info
+
+    def close_env(self):
+        self.env.close()

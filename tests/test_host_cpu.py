@@ -9,6 +9,7 @@ import argparse
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch as th
 import torch.distributed as dist
@@ -133,7 +134,8 @@ def _worker(rank, world, port, q):
         gsum = [float(p.grad.flatten()[0]) for p in lin.parameters()]
         a = _small_args(4)
         flat, losses = _train_once(a, 4 * rank, 4 * rank + 4)
-        q.put((rank, float(mean), float(std), float(x.mean()), float(x.std()), gsum, flat, losses))
+        # plain numpy through the queue: torch tensors travel as shared-memory handles that die with the child
+        q.put((rank, float(mean), float(std), float(x.mean()), float(x.std()), gsum, flat.numpy().copy(), losses))
     finally:
         dist.destroy_process_group()
 
@@ -153,9 +155,122 @@ def test_ppo_data_parallel_gloo_world2():
         assert abs(mean - want_mean) < 1e-6 and abs(std - want_std) < 1e-6   # unbiased std of the whole batch
         assert gsum == [3.0, 3.0]
     # both ranks end with identical parameters ...
-    assert th.equal(got[0][6], got[1][6])
+    assert (got[0][6] == got[1][6]).all()
     # ... equal (to fp32 summation-order noise) to one rank training on the whole batch
     flat1, losses1 = _train_once(_small_args(8), 0, 8)
-    assert th.allclose(got[0][6], flat1, rtol=1e-4, atol=2e-6), float((got[0][6] - flat1).abs().max())
+    assert th.allclose(th.from_numpy(got[0][6]), flat1, rtol=1e-4, atol=2e-6), float((th.from_numpy(got[0][6]) - flat1).abs().max())
     for k in losses1:
         assert abs(got[0][7][k] - losses1[k]) < 1e-5 * max(1.0, abs(losses1[k]))
+
+
+# ---------------------------------------------------------------------------------------------- GAIL / DGAIL host logic
+def test_expert_transitions_fifo():
+    from marl_amd.buffer.expert_transitions import ExpertTransitions
+    st = ExpertTransitions(5, n_agents=2, obs_shape=3, device="cpu")
+    assert len(st) == 0
+    mk = lambda lo, n: (th.arange(lo, lo + n).float().view(n, 1, 1).expand(n, 2, 3).contiguous(),
+                        th.arange(lo, lo + n).view(n, 1).expand(n, 2).contiguous())
+    o, a = mk(0, 4)
+    st.append(o, a, th.tensor([True, False, True, True]))        # stores 0, 2, 3
+    assert len(st) == 3 and st.actions[:3, 0].tolist() == [0, 2, 3]
+    o, a = mk(10, 4)
+    st.append(o, a)                                               # 10..13: ring of 5 wraps, oldest (0, 2) dropped
+    assert len(st) == 5
+    assert sorted(st.actions[:5, 0].tolist()) == [3, 10, 11, 12, 13]
+    assert th.equal(st.obs[:5, 0, 0].long(), st.actions[:5, 0])   # obs and actions stay paired
+    so, sa = st.sample_transitions(64)
+    assert so.shape == (5, 2, 3) and sorted(sa[:, 0].tolist()) == [3, 10, 11, 12, 13]   # without replacement
+    ro, ra = st.sample_rows(1000)
+    assert ro.shape == (1000, 3) and set(ra.tolist()) <= {3, 10, 11, 12, 13}
+    st2 = ExpertTransitions(5, 2, 3, "cpu")
+    st2.load_state_dict(st.state_dict())
+    assert len(st2) == 5 and th.equal(st2.actions[:5], st.actions[:5])
+    st3 = ExpertTransitions(5, 2, 3, "cpu")                       # the reference's list-of-tensors checkpoint layout
+    st3.load_state_dict({"expert_obs": [o[i] for i in range(4)], "expert_actions": [a[i] for i in range(4)]})
+    assert len(st3) == 4
+
+
+def _imitation_args(kind, B):
+    from marl_amd.default_config import add_default_args
+    from marl_amd.envs.edge_computing.multihop.edge_computing_config import add_edge_computing_env_args
+    from marl_amd.agent_register import agent_config_register
+    p = argparse.ArgumentParser(conflict_handler="resolve")
+    p = agent_config_register[kind](add_edge_computing_env_args(add_default_args(p)))
+    a = p.parse_args([])
+    a.n_threads, a.episode_limit, a.n_agents, a.n_actions, a.obs_shape = B, 6, 3, 4, 9
+    a.state_shape, a.device, a.ec_force_device = 27, "cpu", "cpu"
+    return a
+
+
+def _fill_imitation(agent, a, seed=3):
+    g = th.Generator().manual_seed(seed)
+    B, T, N, A = a.n_threads, a.episode_limit, a.n_agents, a.n_actions
+    agent.buffer.reset()
+    for t in range(T):
+        obs = th.rand(B, N, 9, generator=g)
+        avail = th.ones(B, N, A, dtype=th.int)
+        act = th.randint(0, A, (B, N, 1), generator=g)
+        agent.buffer.insert(obs, avail, act, th.randn(B, 1, 1, generator=g).expand(B, N, 1),
+                            th.ones(B, N, 1) * (t < T - 1), th.rand(B, N, 9, generator=g))
+        agent.store_expert_data(obs, th.randint(0, A, (B, N), generator=g), th.rand(B, generator=g) < 0.8)
+
+
+def test_dgail_agent_train_cpu():
+    """reference defaults (dgail_config.py) + one full DGAILAgent.train on CPU tensors with the torch GAE loop."""
+    import marl_amd.rl.policy_gradient_rl.dgail.dgail_agent as da
+    da.get_gae = _torch_gae
+    a = _imitation_args("dgail", 40)
+    assert (a.ppo_batch_size, a.policy_lr, a.entropy_coef, a.value_loss_coef, a.grad_norm_clip) == (64, 2e-5, 8e-4, 0.2, 1.0)
+    assert a.max_expert_buffer_size == 20000 and a.batch_size_run == 100 and a.use_simplified_reward is True
+    th.manual_seed(0)
+    agent = da.DGAILAgent(a)
+    agent._bc_pretrain_steps = 5
+    _fill_imitation(agent, a)
+    assert agent.train(0) is not None or len(agent.expert_transitions) < a.batch_size_run
+    assert len(agent.expert_transitions) >= a.batch_size_run
+    before = [p.detach().clone() for p in agent.policy.parameters()]
+    stats = agent.train(1000)
+    assert set(stats) >= {"discriminator_loss", "gail_discriminator_loss", "prob_expert", "prob_agent",
+                          "avg_imitation_reward", "policy_loss", "value_loss", "entropy"}
+    assert all(np.isfinite(v) for v in stats.values())
+    assert any(not th.equal(b, p) for b, p in zip(before, agent.policy.parameters()))
+    assert agent.update_count >= 1 and agent._bc_pretrain_steps == 0
+    # reward arithmetic of both branches against the formulas of dgail_agent.py:482-518
+    obs, _, actions, env_r, _, _ = agent.buffer.sample()
+    sa = agent._prepare_batch(obs, actions)
+    with th.no_grad():
+        p = agent.gail_discriminator(sa).clamp(1e-8, 1 - 1e-8).squeeze(-1)
+        want = -th.log(1 - p) * (1.0 - 0.2 * min(1.0, 40000 / 80000.0)) + 0.02 * env_r.reshape(-1)
+    got = agent._compute_rewards(obs, actions, env_r, 40000)
+    assert got.shape == (40, 6, 3, 1) and th.allclose(got.reshape(-1), want, rtol=1e-6, atol=1e-7)
+    agent._use_simplified_reward = False
+    r2 = agent._compute_rewards(obs, actions, env_r, 40000)
+    assert r2.shape == got.shape and bool(th.isfinite(r2).all())
+    # schedules, dgail_agent.py:383-401,170-178
+    for _ in range(6):
+        agent.update_performance_monitoring(0.5)
+    assert agent._w_factor > 1.0 and len(agent.performance_history) == 6
+    w = agent.bc_loss_weight
+    agent._update_bc_weight()
+    assert agent.bc_loss_weight == min(2.0, w * 1.1)
+
+
+def test_gail_agent_train_cpu():
+    import marl_amd.rl.policy_gradient_rl.gail.gail_agent as ga
+    ga.get_gae = _torch_gae
+    a = _imitation_args("gail", 16)
+    assert (a.eps_clip, a.lr, a.bc_loss_weight, a.max_expert_buffer_size, a.expert_guidance_steps) == (0.1, 3e-4, 2, 1000, 40000)
+    th.manual_seed(0)
+    agent = ga.GAILAgent(a)
+    assert agent.get_expert_ratio(0) == 1.0 and agent.get_expert_ratio(10 ** 6) == 0.2
+    assert abs(agent.get_expert_ratio(21000) - 0.45) < 1e-12
+    _fill_imitation(agent, a)
+    before = [p.detach().clone() for p in list(agent.actor.parameters()) + list(agent.discriminator.parameters())]
+    agent.train()
+    after = list(agent.actor.parameters()) + list(agent.discriminator.parameters())
+    assert any(not th.equal(b, p) for b, p in zip(before, after))
+    assert all(bool(th.isfinite(v)) for v in agent.last_losses.values()) and "discriminator_loss" in agent.last_losses
+    assert agent.bc_loss_weight == max(a.min_bc_weight, 2 * a.bc_decay_rate)
+    # discriminator layout of gail_network.py:59-132
+    names = [n for n, _ in agent.discriminator.named_parameters()]
+    assert names[:4] == ["fc1.weight", "fc1.bias", "bn1.weight", "bn1.bias"] and agent.discriminator.fc1.in_features == 9 + 3 + 4

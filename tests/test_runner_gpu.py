@@ -141,3 +141,83 @@ def test_fused_select_actions_matches_torch_distribution():
     freq = th.stack([(acts[..., n].reshape(-1, 1) == th.arange(A, device=acts.device)).float().mean(0) for n in range(N)])
     assert float((freq - probs).abs().max()) < 0.012   # ~4 sigma at p=0.5, 32768 draws
     assert float(freq[avail1[0] == 0].sum()) == 0.0
+
+
+def _imitation_args(kind, B, **over):
+    import argparse
+    from marl_amd.agent_register import agent_config_register
+    from marl_amd.default_config import add_default_args
+    from marl_amd.envs.edge_computing.multihop.edge_computing_config import add_edge_computing_env_args
+    p = argparse.ArgumentParser(conflict_handler="resolve")
+    p = agent_config_register[kind](add_edge_computing_env_args(add_default_args(p)))
+    a = p.parse_args(["--task_size_max=6000"])
+    a.n_threads, a.obs_shape, a.n_agents, a.n_actions = B, 9, a.edge_node_num, a.edge_node_num + 1
+    a.state_shape, a.device = 9 * a.edge_node_num, "cuda"
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_dgail_runner_iterations():
+    """DGAILRunner + DGAILAgent end to end on the device: expert-guided rollout (ec_expert_policy), expert store,
+    both discriminator updates, rewards through ec_gail_reward / ec_diffusion_reward, minibatch PPO."""
+    from marl_amd.agent_register import agent_register
+    from marl_amd.runners.runner_register import runner_register
+    B = 32
+    a = _imitation_args("dgail", B, episode_limit=50)
+    th.manual_seed(1)
+    agent = agent_register["dgail"](a)
+    agent._bc_pretrain_steps = 20
+    runner = runner_register["dgail_runner"](a, agent)
+    assert runner._expert_ratio() == 1.0
+    info = runner.run(test_mode=False)
+    T = a.episode_limit
+    assert runner.t_env == B * T and info["episode_steps"] == T
+    # t_env < bc_guidance_steps (2000) during the whole first episode: every step is expert-driven (dgail_runner.py:31-32)
+    assert runner.expert_steps == B * T
+    assert info["expert_buffer_size"] == min(runner.expert_steps, a.max_expert_buffer_size)
+    assert {"discriminator_loss", "gail_discriminator_loss", "policy_loss", "value_loss", "entropy",
+            "avg_imitation_reward"} <= set(info)
+    assert all(np.isfinite(info[k]) for k in ("discriminator_loss", "policy_loss", "avg_imitation_reward", "episode_return"))
+    obs, avail, actions, rewards, masks, next_obs = agent.buffer.sample()
+    assert bool((avail.gather(-1, actions) == 1).all())          # the buffer holds the AGENT's (masked) actions
+    # the expert store holds states in which the expert acted, with the expert's decision for them
+    n = len(agent.expert_transitions)
+    eo, ea = agent.expert_transitions.obs[:n], agent.expert_transitions.actions[:n]
+    no_task = eo[..., 5] < 0
+    assert bool((ea[no_task] == a.n_agents).all()) and bool((ea[~no_task] < a.n_agents).all())
+    # rewards: HIP entry points against the torch formulas, simplified (GAIL discriminator) and diffusion branch
+    env_r = rewards
+    got = agent._compute_rewards(obs, actions, env_r, runner.t_env)
+    want = agent._compute_rewards_torch(obs, actions, env_r, False, agent._imitation_weight(runner.t_env))
+    assert th.allclose(got, want, rtol=2e-4, atol=2e-5)
+    agent._use_simplified_reward = False
+    r_diff = agent._compute_rewards(obs, actions, env_r, runner.t_env)
+    assert r_diff.shape == got.shape and bool(th.isfinite(r_diff).all()) and float(r_diff.std()) > 0
+    agent._use_simplified_reward = True
+    info2 = runner.run(test_mode=False)
+    assert runner.t_env == 2 * B * T and agent.update_count == 2
+    info3 = runner.run(test_mode=True)
+    assert runner.t_env == 2 * B * T and "policy_loss" not in info3 and np.isfinite(info3["success_rate"])
+    runner.close_env()
+
+
+def test_gail_runner_iterations():
+    from marl_amd.agent_register import agent_register
+    from marl_amd.runners.runner_register import runner_register
+    B = 32
+    a = _imitation_args("gail", B, episode_limit=40)
+    th.manual_seed(2)
+    agent = agent_register["gail"](a)
+    runner = runner_register["gail_runner"](a, agent)
+    info = runner.run(test_mode=False, t_expert=0)
+    assert runner.t_env == B * a.episode_limit and agent.update_count == 1
+    assert len(agent.expert_transitions) == min(B * a.episode_limit, a.max_expert_buffer_size)   # ratio 1.0 at t_expert 0
+    assert "discriminator_loss" in agent.last_losses and all(bool(th.isfinite(v)) for v in agent.last_losses.values())
+    assert abs(info["success_rate"] + info["drop_rate"] + info["failure_rate"] - 1.0) < 1e-12
+    # past the guidance window nothing is expert driven and the store stops growing
+    stored = int(agent.expert_transitions._written.item())
+    runner.run(test_mode=False, t_expert=a.expert_guidance_steps)
+    assert int(agent.expert_transitions._written.item()) == stored and agent.update_count == 2
+    runner.run(test_mode=True)
+    runner.close_env()
