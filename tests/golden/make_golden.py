@@ -350,6 +350,90 @@ GROUPS = {"rng": gen_rng, "env10": lambda: gen_env("env10"), "env10d": lambda: g
           "env40": lambda: gen_env("env40"), "gae": gen_gae, "expert10": lambda: gen_expert("expert10"),
           "expert40": lambda: gen_expert("expert40")}
 
+
+
+# --------------------------------------------------------------------------
+def gen_mlp():
+    """Fixtures (5)/(6) of SURVEY 8c from the reference's OWN torch modules: state_dicts + inputs => masked logits /
+    softmax (Actor, PolicyNet), GAIL-discriminator probabilities and rewards, diffusion compute_loss for both
+    conditions with the (t, noise) the reference drew (replayed from the same torch seed), D_phi and reward."""
+    import numpy as np
+    import torch as th
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from rl.policy_gradient_rl.ppo.ppo_network import Actor
+    from rl.policy_gradient_rl.dgail.dgail_network import PolicyNet, GAILDiscriminator, DiffusionDiscriminator
+    out = {}
+    for N in (10, 40):
+        A, SA, rows = N + 1, 9 + N + 1, 640 if N == 10 else 333
+        tag = "n%d_" % N
+        g = th.Generator().manual_seed(1000 + N)
+        obs = th.rand(rows, 9, generator=g)
+        obs[:, 3] *= 6.0
+        obs[:, 8] = th.randint(0, 4, (rows,), generator=g).float()
+        avail = (th.rand(rows, A, generator=g) < 0.6).int()
+        avail[:, 0] = 1
+        actions = th.randint(0, A, (rows,), generator=g)
+        ids = th.eye(N)[th.arange(rows) % N]
+        out[tag + "obs"], out[tag + "avail"], out[tag + "actions"] = obs.numpy(), avail.numpy(), actions.numpy()
+        # --- PPO Actor (ppo_network.py:6-25) and DGAIL PolicyNet (dgail_network.py:6-19)
+        th.manual_seed(7 + N)
+        ns = argparse.Namespace(obs_shape=9, n_agents=N, n_actions=A, hidden_dim=64, activate_fun="relu",
+                                use_orthogonal_init=False)
+        for name, net in (("actor", Actor(ns)), ("policy", PolicyNet(9 + N, A, 64))):
+            with th.no_grad():
+                for p in net.parameters():
+                    p.mul_(3.0)
+                logits = net(th.cat([obs, ids], dim=-1))
+                logits[avail == 0] = -1e10                       # ppo_agent.py:69, dgail_agent.py:122
+                probs = th.softmax(logits, dim=-1)
+            for k, v in net.state_dict().items():
+                out[tag + name + "_sd_" + k] = v.numpy()
+            out[tag + name + "_logits"], out[tag + name + "_probs"] = logits.numpy(), probs.numpy()
+        # --- GAIL discriminator reward (dgail_network.py:37-50, dgail_agent.py:482-485,501-518)
+        sa = th.cat([obs, th.nn.functional.one_hot(actions, A).float()], dim=-1)
+        gd = GAILDiscriminator(SA, 64)
+        with th.no_grad():
+            for p in gd.parameters():
+                p.mul_(2.0)
+            p_ = gd(sa)
+            base = -th.log(1.0 - p_.clamp(1e-8, 1 - 1e-8)).squeeze(-1)
+        for k, v in gd.state_dict().items():
+            out[tag + "gd_sd_" + k] = v.numpy()
+        out[tag + "gd_prob"], out[tag + "gd_base_reward"] = p_.squeeze(-1).numpy(), base.numpy()
+        # --- diffusion discriminator (dgail_network.py:53-108, dgail_agent.py:487-499)
+        dd = DiffusionDiscriminator(SA, 64)
+        with th.no_grad():
+            dd.mlp[4].weight.mul_(3.0)
+        dd.eval()                                                 # spectral norm: stored u/v, no power iteration
+        losses = {}
+        for cname, cval, seed in (("expert", 1, 11), ("agent", 0, 12)):
+            c = th.full((rows,), cval, dtype=th.long)
+            th.manual_seed(seed)                                  # compute_loss draws t then noise (:90-91)
+            L = dd.compute_loss(sa, c).detach()
+            th.manual_seed(seed)
+            t = th.randint(0, 2, (rows,))
+            noise = th.randn_like(sa)
+            losses[cname] = L
+            out[tag + "dd_t_" + cname], out[tag + "dd_noise_" + cname] = t.numpy().astype(np.uint8), noise.numpy()
+            out[tag + "dd_loss_" + cname] = L.numpy()
+        pe, pa = th.exp(-losses["expert"]), th.exp(-losses["agent"])
+        dphi = pe / (pe + pa + 1e-8)
+        out[tag + "dd_dphi"], out[tag + "dd_reward"] = dphi.numpy(), (-th.log(1 - dphi + 1e-8)).numpy()
+        # effective (spectrally normalised) weights as the module computes them
+        out[tag + "dd_w1"], out[tag + "dd_b1"] = dd.mlp[0].weight.detach().numpy(), dd.mlp[0].bias.detach().numpy()
+        out[tag + "dd_w2"], out[tag + "dd_b2"] = dd.mlp[2].weight.detach().numpy(), dd.mlp[2].bias.detach().numpy()
+        out[tag + "dd_w3"], out[tag + "dd_b3"] = dd.mlp[4].weight.detach().numpy(), dd.mlp[4].bias.detach().numpy()
+        out[tag + "dd_time_embed"] = dd.time_embed.weight.detach().numpy()
+        out[tag + "dd_cond_embed"] = dd.cond_embed.weight.detach().numpy()
+        for k, v in dd.state_dict().items():
+            out[tag + "dd_sd_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "mlp.npz"), **out)
+
+
+GROUPS["mlp"] = gen_mlp
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         GROUPS[sys.argv[1]]()

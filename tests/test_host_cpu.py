@@ -274,3 +274,39 @@ def test_gail_agent_train_cpu():
     # discriminator layout of gail_network.py:59-132
     names = [n for n, _ in agent.discriminator.named_parameters()]
     assert names[:4] == ["fc1.weight", "fc1.bias", "bn1.weight", "bn1.bias"] and agent.discriminator.fc1.in_features == 9 + 3 + 4
+
+
+@pytest.mark.parametrize("N", [10, 40])
+def test_network_mirrors_match_reference_fixtures(N):
+    """The package's torch modules load the REFERENCE's state_dicts (same parameter names) and reproduce the outputs
+    the reference's own modules produced (tests/golden/mlp.npz, made by importing rl/policy_gradient_rl/...)."""
+    from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import DiffusionDiscriminator, GAILDiscriminator, PolicyNet
+    from marl_amd.rl.policy_gradient_rl.ppo.ppo_network import Actor
+    from tests.util import load_golden
+    g = load_golden("mlp")
+    tag = "n%d_" % N
+    A, SA = N + 1, 10 + N
+    obs, avail, actions = (th.from_numpy(g[tag + k]) for k in ("obs", "avail", "actions"))
+    rows = obs.shape[0]
+    ids = th.eye(N)[th.arange(rows) % N]
+    sd = lambda name: {k[len(tag + name + "_sd_"):]: th.from_numpy(g[k]) for k in g.files if k.startswith(tag + name + "_sd_")}
+    ns = argparse.Namespace(obs_shape=9, n_agents=N, n_actions=A, hidden_dim=64, activate_fun="relu", use_orthogonal_init=False)
+    for name, net in (("actor", Actor(ns)), ("policy", PolicyNet(9 + N, A, 64))):
+        net.load_state_dict(sd(name))
+        with th.no_grad():
+            logits = net(th.cat([obs, ids], -1))
+        logits[avail == 0] = -1e10
+        assert th.allclose(logits, th.from_numpy(g[tag + name + "_logits"]), rtol=1e-6, atol=1e-6)
+    sa = th.cat([obs, th.nn.functional.one_hot(actions, A).float()], -1)
+    gd = GAILDiscriminator(SA, 64)
+    gd.load_state_dict(sd("gd"))
+    with th.no_grad():
+        assert th.allclose(gd(sa).squeeze(-1), th.from_numpy(g[tag + "gd_prob"]), rtol=1e-6, atol=1e-7)
+    dd = DiffusionDiscriminator(SA, 64)
+    dd.load_state_dict(sd("dd"))
+    dd.eval()
+    assert th.allclose(dd.mlp[0].weight, th.from_numpy(g[tag + "dd_w1"]), rtol=1e-6, atol=1e-7)   # effective weights
+    for cname, cval in (("expert", 1), ("agent", 0)):
+        L = dd.compute_loss(sa, th.full((rows,), cval, dtype=th.long), th.from_numpy(g[tag + "dd_t_" + cname]).long(),
+                            th.from_numpy(g[tag + "dd_noise_" + cname])).detach()
+        assert th.allclose(L, th.from_numpy(g[tag + "dd_loss_" + cname]), rtol=1e-5, atol=1e-6)

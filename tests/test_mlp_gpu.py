@@ -235,3 +235,38 @@ def test_diffusion_reward_reference_lambda():
                                       n_a.to(dev))
     _close(got[0], Le, "loss(expert)")
     _close(got[1], La, "loss(agent)")
+
+
+@pytest.mark.parametrize("N", [10, 40])
+def test_reference_fixtures(N):
+    """The three entry points against outputs of the REFERENCE's own torch modules (tests/golden/mlp.npz, generated by
+    importing rl/policy_gradient_rl/{ppo,dgail} — fp32 torch on the CPU), to the north star's 1e-5 relative."""
+    from marl_amd.utils import mlp_device
+    from tests.util import load_golden
+    dev = _dev()
+    g = load_golden("mlp")
+    tag = "n%d_" % N
+    A = N + 1
+    T = lambda k: th.from_numpy(g[tag + k]).to(dev)
+    obs, avail, actions = T("obs"), T("avail"), T("actions")
+    for name, keys in (("actor", ("fc1", "fc2", "fc3")), ("policy", ("model.0", "model.2", "model.4"))):
+        params = tuple(T("%s_sd_%s.%s" % (name, k, wb)) for k in keys for wb in ("weight", "bias"))
+        lg, pr, _ = mlp_device.policy_forward(params, obs, N, avail, None, want_logits=True)
+        _close(lg, T(name + "_logits"), name + " logits", rtol=1e-5, atol=5e-6)
+        _close(pr, T(name + "_probs"), name + " probs", rtol=1e-5, atol=1e-6)
+    gp = tuple(T("gd_sd_model.%d.%s" % (i, wb)) for i in (0, 2, 4) for wb in ("weight", "bias"))
+    out, prob = mlp_device.gail_reward(gp, obs, actions, A, weight=1.0, want_prob=True)
+    _close(prob, T("gd_prob"), "GAIL D(s,a)", rtol=1e-5, atol=1e-6)
+    ok = T("gd_prob") < 0.999
+    _close(out[ok], T("gd_base_reward")[ok], "GAIL reward", rtol=2e-4, atol=1e-5)
+    dp = tuple(T("dd_" + k) for k in ("w1", "b1", "w2", "b2", "w3", "b3"))
+    Le, La, dphi, rew = mlp_device.diffusion_reward(dp, T("dd_time_embed"), T("dd_cond_embed"), obs, actions, A,
+                                                    T("dd_t_expert"), T("dd_noise_expert"), T("dd_t_agent"),
+                                                    T("dd_noise_agent"))
+    _close(Le, T("dd_loss_expert"), "diffusion loss (expert)", rtol=1e-5, atol=2e-6)
+    _close(La, T("dd_loss_agent"), "diffusion loss (agent)", rtol=1e-5, atol=2e-6)
+    # D_phi / reward amplify differences of the two losses: compare where the reference's own fp32 is conditioned
+    want_d = T("dd_dphi")
+    well = (want_d > 1e-3) & (want_d < 0.99)
+    _close(dphi[well], want_d[well], "D_phi", rtol=1e-4, atol=1e-6)
+    _close(rew[well], T("dd_reward")[well], "reward", rtol=2e-3, atol=1e-5)
