@@ -185,6 +185,31 @@ int ec_diffusion_reward(const float* w1, const float* b1, const float* w2, const
                         int32_t hidden, float r1_lambda, float* loss_expert, float* loss_agent, float* d_phi,
                         float* reward, void* stream);
 
+/* --- fused PPO loss + gradients ----------------------------------------------------------------------------------
+ * One launch per network does the forward pass, the loss and the whole backward pass of the (obs | one-hot agent id)
+ * -> 64 -> 64 -> {n_actions, 1} MLP over `rows` = B*T*n_agents rows (row r is agent r % n_agents) and ACCUMULATES
+ *   grads  flat f32 [dW1 | db1 | dW2 | db2 | dW3 | db3] in torch's parameter order (zero it first)
+ *   loss   f32 [1]: the rank's share of the loss (numerator over the global denominator)
+ * Agreement with torch autograd: 1e-4 relative on the gradient (fp32, different summation order, atomics).
+ *
+ * Actor: replaces evaluate_actions + the clipped-surrogate/entropy objective + backward of
+ * rl/policy_gradient_rl/ppo/ppo_agent.py:76-83,123,135-147 (identical in gail_agent.py:109-116,199-226):
+ *   logits masked to -1e10 where avail == 0, softmax, Categorical(probs) log-prob / entropy (probabilities clamped to
+ *   [eps, 1-eps] as torch does), ratio = exp(logp - old_logp), objective = min(ratio*adv, clip(ratio)*adv)
+ *   + entropy_coef * entropy, loss = -sum(objective * mask) * inv_denom.
+ *   old_logp == NULL: forward only (logp / entropy out: the no-grad evaluate_actions of :113); grads == NULL: loss only.
+ * Critic: replaces ppo_agent.py:124-131: loss = sum(((v - target) * mask)^2) * inv_denom.
+ *   target == NULL: forward only (values out: the no-grad critic passes of :114-115). */
+int ec_ppo_actor_grad(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                      const float* b3, const float* obs, const int32_t* avail, const int64_t* actions,
+                      const float* old_logp, const float* adv, const float* mask, int64_t rows, int32_t n_agents,
+                      int32_t n_actions, int32_t hidden, float eps_clip, float entropy_coef, float inv_denom,
+                      float* grads, float* loss, float* logp, float* entropy, void* stream);
+int ec_ppo_critic_grad(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                       const float* b3, const float* obs, const float* target, const float* mask, int64_t rows,
+                       int32_t n_agents, int32_t hidden, float inv_denom, float* grads, float* loss, float* values,
+                       void* stream);
+
 const char* ec_last_error(void);
 const char* ec_version(void);
 

@@ -1,0 +1,491 @@
+// ec_ppo.hip — fused forward + loss + backward of the PPO actor and critic (obs | one-hot agent id) -> 64 -> 64 -> {A, 1}
+// MLPs over the whole rollout batch, gfx950.
+//
+// Replaces, per optimiser step of PPOAgent.train (rl/policy_gradient_rl/ppo/ppo_agent.py:104-134; same losses in
+// gail_agent.py:198-226): evaluate_actions (:76-83 — masked softmax, Categorical log-prob and entropy), the clipped
+// surrogate + entropy objective, the masked critic MSE, and the autograd backward of both nets.  One launch per net
+// reads 76 B (actor) / 48 B (critic) per row and writes the parameter gradients; nothing per-row is materialised in HBM
+// (the torch path streams ~60 [rows,64] fp32 tensors per epoch and spends most of its time in split-K-less weight-
+// gradient GEMMs and bias reductions over 4 M rows).
+//
+// Scheme (fp32 MFMA 32x32x2, a wave owns 32 rows per pass; see ec_mlp.hip for the forward chaining):
+//   forward      h1 = W1x.obs + b1 + W1id[:, agent];  h2 = W2.relu(h1) + b2;  out = W3.relu(h2) + b3
+//   head         per row in registers (the row's outputs live in lanes l and l^32): softmax / log-prob / entropy /
+//                ratio / clip (actor) or squared error (critic) and d loss / d out
+//   backward     d2 = (W3^T d3) .* [h2>0],  d1 = (W2^T d2) .* [h1>0]   — the same register chaining on transposed
+//                fragments
+//   weight grads dW = sum_rows d (x) act: the row index is the MFMA's K dimension, so d and act are transposed through
+//                a per-wave LDS tile ([index][row], stride 33) and accumulated in persistent MFMA accumulators; bias
+//                gradients ride along as a per-lane running sum of the A operand.  One atomic add per accumulator
+//                register at the end of the wave's row loop.
+#include "ec_mfma.h"
+
+namespace {
+
+constexpr float EPS32 = 1.1920929e-07f;  // torch.finfo(float32).eps: Categorical clamps probs to [eps, 1-eps]
+constexpr int TS = 33;                   // row stride of the transposition tiles
+
+// out[to] += frag * f(in): TI input tiles of 16 accumulator registers (k order kperm), one group of 32 rows
+template <int TO, int TI, typename F>
+__device__ __forceinline__ void chain(f32x16 (&out)[TO], const float* __restrict__ frag, const f32x16 (&in)[TI], int lane, F f) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4 * TI; s4++) {
+#pragma unroll
+        for (int to = 0; to < TO; to++) {
+            const float4 a = *reinterpret_cast<const float4*>(frag + ((s4 * TO + to) * 64 + lane) * 4);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int T = s4 >> 2, r = (s4 & 3) * 4 + c;
+                out[to] = MFMA(av[c], f(T, r, in[T][r]), out[to]);
+            }
+        }
+    }
+}
+
+// first layer over the 9 observation inputs of the wave's 32 rows (s_obs [32][9])
+__device__ __forceinline__ void chain_obs(f32x16 (&out)[2], const float* __restrict__ frag, const float* __restrict__ s_obs, int lane) {
+    const int jrow = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int s4 = 0; s4 < 2; s4++) {
+#pragma unroll
+        for (int to = 0; to < 2; to++) {
+            const float4 a = *reinterpret_cast<const float4*>(frag + ((s4 * 2 + to) * 64 + lane) * 4);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int s = 4 * s4 + c;
+                if (s < 5) {
+                    const int k = 2 * s + half;
+                    out[to] = MFMA(av[c], k < OBS ? s_obs[jrow * OBS + k] : 0.0f, out[to]);
+                }
+            }
+        }
+    }
+}
+
+// accumulator-layout registers -> transposition tile [index][row]
+template <int T, typename F>
+__device__ __forceinline__ void put_tile(float* __restrict__ tile, const f32x16 (&v)[T], int lane, F f) {
+    const int jrow = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) tile[(32 * t + 8 * (r >> 2) + 4 * half + (r & 3)) * TS + jrow] = f(t, r, v[t][r]);
+}
+
+// acc[to][ti] += Td[out][row] (x) Ta[in][row] over the tile's 32 rows; dbias[to] += sum_rows Td[out][row] (lane's parity)
+template <int TO, int TI>
+__device__ __forceinline__ void wgrad(f32x16 (&acc)[TO][TI], float (&dbias)[TO], const float* __restrict__ Td,
+                                      const float* __restrict__ Ta, int lane) {
+    const int i = lane & 31, half = lane >> 5;
+#pragma unroll 4
+    for (int s = 0; s < 16; s++) {
+        const int row = 2 * s + half;
+        float a[TO], b[TI];
+#pragma unroll
+        for (int to = 0; to < TO; to++) {
+            a[to] = Td[(32 * to + i) * TS + row];
+            dbias[to] += a[to];
+        }
+#pragma unroll
+        for (int ti = 0; ti < TI; ti++) b[ti] = Ta[(32 * ti + i) * TS + row];
+#pragma unroll
+        for (int to = 0; to < TO; to++)
+#pragma unroll
+            for (int ti = 0; ti < TI; ti++) acc[to][ti] = MFMA(a[to], b[ti], acc[to][ti]);
+    }
+}
+
+// flush an accumulator tile pair into a row-major [n_out][ld] gradient with atomics
+template <int TO, int TI>
+__device__ __forceinline__ void flush(float* __restrict__ g, int ld, int n_out, int n_in, const f32x16 (&acc)[TO][TI], int lane) {
+    const int j = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int to = 0; to < TO; to++)
+#pragma unroll
+        for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int out = 32 * to + 8 * (r >> 2) + 4 * half + (r & 3), in = 32 * ti + j;
+                if (out < n_out && in < n_in) atomicAdd(g + (size_t)out * ld + in, acc[to][ti][r]);
+            }
+}
+
+struct PpoArgs {
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+    const float* obs;        // [R,9]
+    const int32_t* avail;    // [R,A] (actor)
+    const int64_t* actions;  // [R]   (actor)
+    const float* old_logp;   // [R]   (actor; NULL: forward only)
+    const float* adv;        // [R]   (actor)
+    const float* target;     // [R]   (critic)
+    const float* mask;       // [R]
+    int64_t R;
+    int n_agents, A;
+    float eps_clip, entropy_coef, inv_denom;
+    float* grads;     // flat [dW1 | db1 | dW2 | db2 | dW3 | db3] (torch parameter order), accumulated into; NULL: no backward
+    float* loss;      // [1] accumulated into
+    float* out_a;     // actor: log-prob of the taken action [R]; critic: value [R]
+    float* out_b;     // actor: entropy [R]
+};
+
+// HEAD 0: actor (TO3 output tiles), HEAD 1: critic.  IN1T: tiles of the first layer's dense input (9 + n_agents).
+template <int HEAD, int TO3, int IN1T>
+__global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
+    extern __shared__ __align__(16) float lds[];
+    const int nw = blockDim.x >> 6;
+    const int N = p.n_agents, A = p.A, in1 = OBS + N;
+    constexpr int T3 = HEAD == 0 ? TO3 : 1;
+    float* s_f1 = lds;                          // W1 obs part: 8 steps x 2
+    float* s_f2 = s_f1 + 8 * 2 * 64;            // W2: 32 x 2
+    float* s_f2t = s_f2 + 32 * 2 * 64;          // W2^T: 32 x 2
+    float* s_f3 = s_f2t + 32 * 2 * 64;          // actor W3: 32 x TO3;   critic: w3 [64]
+    float* s_f3t = s_f3 + (HEAD == 0 ? 32 * TO3 * 64 : 64);  // actor W3^T: 16*TO3 x 2
+    float* s_b1 = s_f3t + (HEAD == 0 ? 16 * TO3 * 2 * 64 : 0);
+    float* s_b2 = s_b1 + H;
+    float* s_b3 = s_b2 + H;                     // [32*T3]
+    float* s_id = s_b3 + 32 * T3;               // [N][64]
+    float* s_wave = s_id + (size_t)N * H;
+    stage_frag(s_f1, p.w1, in1, 1, H, OBS, 8, 2, false);
+    stage_frag(s_f2, p.w2, H, 1, H, H, 32, 2, true);
+    stage_frag(s_f2t, p.w2, 1, H, H, H, 32, 2, true);  // M[out=j][k=i] = W2[i][j]
+    if (HEAD == 0) {
+        stage_frag(s_f3, p.w3, H, 1, A, H, 32, TO3, true);
+        stage_frag(s_f3t, p.w3, 1, H, H, A, 16 * TO3, 2, true);  // M[out=j][k=a] = W3[a][j]
+    } else {
+        for (int i = threadIdx.x; i < H; i += blockDim.x) s_f3[i] = p.w3[i];
+    }
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        s_b1[i] = p.b1[i];
+        s_b2[i] = p.b2[i];
+    }
+    for (int i = threadIdx.x; i < 32 * T3; i += blockDim.x) s_b3[i] = i < (HEAD == 0 ? A : 1) ? p.b3[i] : 0.0f;
+    for (int i = threadIdx.x; i < N * H; i += blockDim.x) {
+        const int ag = i / H, o = i - ag * H;
+        s_id[i] = p.w1[(size_t)o * in1 + OBS + ag];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int jrow = lane & 31, half = lane >> 5;
+    const int availw = HEAD == 0 ? 32 * A : 0;
+    float* s_obs = s_wave + (size_t)wave * (32 * OBS + 4 + availw + 2 * 64 * TS);
+    int32_t* s_av = reinterpret_cast<int32_t*>(s_obs + 32 * OBS + 4);
+    float* Td = s_obs + 32 * OBS + 4 + availw;
+    float* Ta = Td + 64 * TS;
+    const bool backward = p.grads != nullptr;
+
+    // persistent gradient accumulators of this wave
+    f32x16 gW1[2][IN1T], gW2[2][2], gW3[T3][2];
+    float gb1[2] = {0.0f, 0.0f}, gb2[2] = {0.0f, 0.0f}, gb3[T3];
+    float gb3c = 0.0f, loss_acc = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+#pragma unroll
+        for (int b = 0; b < IN1T; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) gW1[a][b][r] = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) gW2[a][b][r] = 0.0f;
+    }
+#pragma unroll
+    for (int a = 0; a < T3; a++) {
+        gb3[a] = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) gW3[a][b][r] = 0.0f;
+    }
+
+    const int64_t n_tiles = (p.R + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += (int64_t)gridDim.x * nw) {
+        const int64_t rowbase = tile * 32;
+        const int64_t row = rowbase + jrow;
+        const bool ok = row < p.R;
+        wave_sync();
+        {
+            const int64_t nvalid = (p.R - rowbase < 32 ? p.R - rowbase : 32);
+            for (int i = lane; i < 32 * OBS; i += 64) s_obs[i] = i < nvalid * OBS ? p.obs[rowbase * OBS + i] : 0.0f;
+            if (HEAD == 0)
+                for (int i = lane; i < 32 * A; i += 64) s_av[i] = i < nvalid * A ? p.avail[rowbase * A + i] : 0;
+        }
+        wave_sync();
+        const int agent = ok ? (int)(row % N) : 0;  // one-hot agent id (ppo_agent.py:64-65)
+        const float m = ok ? p.mask[row] : 0.0f;
+
+        // ------------------------------------------------------------------ forward
+        f32x16 h1[2], h2[2];
+        acc_init<2>(h1, s_b1, half);
+        acc_add<2>(h1, s_id + agent * H, half);
+        acc_init<2>(h2, s_b2, half);
+        chain_obs(h1, s_f1, s_obs, lane);
+        chain<2, 2>(h2, s_f2, h1, lane, [](int, int, float x) { return relu(x); });
+
+        f32x16 d2[2];  // d loss / d h2 (pre-activation), accumulator layout
+        if (HEAD == 0) {
+            f32x16 z[T3];
+            acc_init<T3>(z, s_b3, half);
+            chain<T3, 2>(z, s_f3, h2, lane, [](int, int, float x) { return relu(x); });
+            // ---- head: masked softmax, Categorical log-prob / entropy, clipped surrogate (ppo_agent.py:76-83,135-141)
+            const int act = ok ? (int)p.actions[row] : 0;
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int t = 0; t < T3; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int j = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
+                    float x = z[t][r];
+                    if (j < A) {
+                        if (s_av[jrow * A + j] == 0) x = -1e10f;
+                        mx = fmaxf(mx, x);
+                    }
+                    z[t][r] = x;
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.0f;
+#pragma unroll
+            for (int t = 0; t < T3; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int j = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
+                    const float e = j < A ? expf(z[t][r] - mx) : 0.0f;
+                    z[t][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            float Hent = 0.0f, gbar = 0.0f, lp_a = 0.0f, inr_a = 0.0f;
+            f32x16 gk[T3];  // dH/dp_k
+#pragma unroll
+            for (int t = 0; t < T3; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int j = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
+                    const float pj = z[t][r] * inv;
+                    const bool inr = pj >= EPS32 && pj <= 1.0f - EPS32;
+                    const float lp = logf(fminf(fmaxf(pj, EPS32), 1.0f - EPS32));
+                    z[t][r] = pj;
+                    const float g = j < A ? -(lp + (inr ? 1.0f : 0.0f)) : 0.0f;
+                    gk[t][r] = g;
+                    Hent = j < A ? fmaf(-pj, lp, Hent) : Hent;
+                    gbar = fmaf(g, pj, gbar);
+                    if (j == act) {
+                        lp_a = lp;
+                        inr_a = inr ? 1.0f : 0.0f;
+                    }
+                }
+            Hent += __shfl_xor(Hent, 32);
+            gbar += __shfl_xor(gbar, 32);
+            lp_a += __shfl_xor(lp_a, 32);
+            inr_a += __shfl_xor(inr_a, 32);
+            if (ok && half == 0) {
+                if (p.out_a) p.out_a[row] = lp_a;
+                if (p.out_b) p.out_b[row] = Hent;
+            }
+            if (!p.old_logp) continue;  // forward only
+            const float advr = ok ? p.adv[row] : 0.0f;
+            const float ratio = expf(lp_a - (ok ? p.old_logp[row] : 0.0f));
+            const float lo = 1.0f - p.eps_clip, hi = 1.0f + p.eps_clip;
+            const float surr1 = ratio * advr, surr2 = fminf(fmaxf(ratio, lo), hi) * advr;
+            const float inrange = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+            const float obj = fminf(surr1, surr2) + p.entropy_coef * Hent;
+            if (half == 0) loss_acc = fmaf(-obj * m, p.inv_denom, loss_acc);
+            if (!backward) continue;
+            // torch.min backward: the smaller input takes the gradient, a tie splits it (ratio inside the clip range)
+            const float gr = surr1 < surr2 ? advr : (surr1 > surr2 ? advr * inrange : advr * 0.5f * (1.0f + inrange));
+            const float c1 = gr * ratio * inr_a;
+            const float scale = -m * p.inv_denom;
+#pragma unroll
+            for (int t = 0; t < T3; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int j = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
+                    const float pj = z[t][r];
+                    const float dz = c1 * ((j == act ? 1.0f : 0.0f) - pj) + p.entropy_coef * pj * (gk[t][r] - gbar);
+                    z[t][r] = j < A ? scale * dz : 0.0f;  // d3
+                }
+            // dW3 += d3 (x) relu(h2)
+            wave_sync();
+            put_tile<T3>(Td, z, lane, [](int, int, float x) { return x; });
+            put_tile<2>(Ta, h2, lane, [](int, int, float x) { return relu(x); });
+            wave_sync();
+            wgrad<T3, 2>(gW3, gb3, Td, Ta, lane);
+            // d2 = (W3^T d3) .* [h2 > 0]
+            acc_zero<2>(d2);
+            chain<2, T3>(d2, s_f3t, z, lane, [](int, int, float x) { return x; });
+        } else {
+            // ---- critic head: v = w3 . relu(h2) + b3 ; loss = ((v - target) * mask)^2 / denom (ppo_agent.py:124-125)
+            float part = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float4 w = *reinterpret_cast<const float4*>(s_f3 + 32 * t + 8 * q + 4 * half);
+                    part = fmaf(w.x, relu(h2[t][4 * q + 0]), part);
+                    part = fmaf(w.y, relu(h2[t][4 * q + 1]), part);
+                    part = fmaf(w.z, relu(h2[t][4 * q + 2]), part);
+                    part = fmaf(w.w, relu(h2[t][4 * q + 3]), part);
+                }
+            const float v = part + __shfl_xor(part, 32) + s_b3[0];
+            if (ok && half == 0 && p.out_a) p.out_a[row] = v;
+            if (!p.target) continue;  // forward only
+            const float err = (v - (ok ? p.target[row] : 0.0f)) * m;
+            if (half == 0) loss_acc = fmaf(err * err, p.inv_denom, loss_acc);
+            if (!backward) continue;
+            const float dv = 2.0f * err * m * p.inv_denom;
+            if (half == 0) gb3c += dv;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float4 w = *reinterpret_cast<const float4*>(s_f3 + 32 * t + 8 * q + 4 * half);
+                    const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const float a2 = h2[t][4 * q + c];
+                        gW3[0][t][4 * q + c] = fmaf(dv, relu(a2), gW3[0][t][4 * q + c]);  // per-lane partial of dW3[j]
+                        d2[t][4 * q + c] = a2 > 0.0f ? dv * wv[c] : 0.0f;
+                    }
+                }
+        }
+        if (HEAD == 0) {
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) d2[t][r] = h2[t][r] > 0.0f ? d2[t][r] : 0.0f;
+        }
+        // dW2 += d2 (x) relu(h1)
+        wave_sync();
+        put_tile<2>(Td, d2, lane, [](int, int, float x) { return x; });
+        put_tile<2>(Ta, h1, lane, [](int, int, float x) { return relu(x); });
+        wave_sync();
+        wgrad<2, 2>(gW2, gb2, Td, Ta, lane);
+        // d1 = (W2^T d2) .* [h1 > 0]
+        f32x16 d1[2];
+        acc_zero<2>(d1);
+        chain<2, 2>(d1, s_f2t, d2, lane, [](int, int, float x) { return x; });
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) d1[t][r] = h1[t][r] > 0.0f ? d1[t][r] : 0.0f;
+        // dW1 += d1 (x) (obs | one-hot agent id)
+        wave_sync();
+        put_tile<2>(Td, d1, lane, [](int, int, float x) { return x; });
+        for (int in = half; in < 32 * IN1T; in += 2)
+            Ta[in * TS + jrow] = in < OBS ? s_obs[jrow * OBS + in] : ((ok && in - OBS == agent) ? 1.0f : 0.0f);
+        wave_sync();
+        wgrad<2, IN1T>(gW1, gb1, Td, Ta, lane);
+    }
+
+    // ------------------------------------------------------------------ flush this wave's partial sums
+    if (p.loss && loss_acc != 0.0f) atomicAdd(p.loss, loss_acc);
+    if (backward) {
+        float* g = p.grads;
+        float* gW1p = g;
+        float* gb1p = gW1p + (size_t)H * in1;
+        float* gW2p = gb1p + H;
+        float* gb2p = gW2p + H * H;
+        float* gW3p = gb2p + H;
+        const int n3 = HEAD == 0 ? A : 1;
+        float* gb3p = gW3p + (size_t)n3 * H;
+        flush<2, IN1T>(gW1p, in1, H, in1, gW1, lane);
+        flush<2, 2>(gW2p, H, H, H, gW2, lane);
+#pragma unroll
+        for (int to = 0; to < 2; to++) {
+            atomicAdd(gb1p + 32 * to + (lane & 31), gb1[to]);
+            atomicAdd(gb2p + 32 * to + (lane & 31), gb2[to]);
+        }
+        if (HEAD == 0) {
+            flush<T3, 2>(gW3p, H, A, H, gW3, lane);
+#pragma unroll
+            for (int to = 0; to < T3; to++)
+                if (32 * to + (lane & 31) < A) atomicAdd(gb3p + 32 * to + (lane & 31), gb3[to]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) atomicAdd(gW3p + 32 * t + 8 * (r >> 2) + 4 * half + (r & 3), gW3[0][t][r]);
+            if (gb3c != 0.0f) atomicAdd(gb3p, gb3c);
+        }
+    }
+}
+
+constexpr size_t PPO_LDS_MAX = 160 * 1024;
+
+size_t ppo_lds_bytes(int head, int TO3, int N, int A, int nw) {
+    size_t f = 8 * 2 * 64 + 2 * (32 * 2 * 64);
+    f += head == 0 ? (size_t)32 * TO3 * 64 + (size_t)16 * TO3 * 2 * 64 : 64;
+    f += 2 * H + 32 * (head == 0 ? TO3 : 1) + (size_t)N * H;
+    const size_t per_wave = 32 * OBS + 4 + (head == 0 ? 32 * A : 0) + 2 * 64 * TS;
+    return sizeof(float) * (f + nw * per_wave);
+}
+
+template <int HEAD, int TO3, int IN1T>
+int launch_ppo(const PpoArgs& a, hipStream_t stream) {
+    int nw = 4;
+    size_t lds = ppo_lds_bytes(HEAD, TO3, a.n_agents, a.A, nw);
+    if (lds > PPO_LDS_MAX) {
+        nw = 2;
+        lds = ppo_lds_bytes(HEAD, TO3, a.n_agents, a.A, nw);
+    }
+    if (lds > PPO_LDS_MAX) return ec::fail(EC_EINVAL, "ec_ppo: %d agents need %zu B of LDS", a.n_agents, lds);
+    EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ppo<HEAD, TO3, IN1T>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t tiles = (a.R + 31) / 32;
+    int64_t blocks = (tiles + nw - 1) / nw;
+    if (blocks > 256) blocks = 256;  // one block per CU: the row loop amortises weight staging and the final atomics
+    hipLaunchKernelGGL((k_ppo<HEAD, TO3, IN1T>), dim3((unsigned)blocks), dim3(64 * nw), lds, stream, a);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+int check_common(const char* what, const void* const* ptrs, int n, int64_t rows, int hidden, int n_agents) {
+    for (int i = 0; i < n; i++)
+        if (!ptrs[i]) return ec::fail(EC_EINVAL, "%s: null pointer", what);
+    if (rows < 0) return ec::fail(EC_EINVAL, "%s: rows < 0", what);
+    if (hidden != H) return ec::fail(EC_EINVAL, "%s: hidden_dim %d unsupported (this build: %d)", what, hidden, H);
+    if (n_agents < 1 || OBS + n_agents > 64) return ec::fail(EC_EINVAL, "%s: 9 + n_agents = %d exceeds 64", what, OBS + n_agents);
+    return EC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ec_ppo_actor_grad(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                      const float* obs, const int32_t* avail, const int64_t* actions, const float* old_logp,
+                      const float* adv, const float* mask, int64_t rows, int32_t n_agents, int32_t n_actions,
+                      int32_t hidden, float eps_clip, float entropy_coef, float inv_denom, float* grads, float* loss,
+                      float* logp, float* entropy, void* stream) {
+    if (rows == 0) return EC_OK;
+    const void* need[] = {w1, b1, w2, b2, w3, b3, obs, avail, actions, mask};
+    if (int rc = check_common("ec_ppo_actor_grad", need, 10, rows, hidden, n_agents)) return rc;
+    if (n_actions < 1 || n_actions > 64) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: n_actions %d out of range [1,64]", n_actions);
+    if (old_logp && !adv) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: old_logp without adv");
+    if (grads && !old_logp) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: grads without old_logp");
+    PpoArgs a{w1, b1, w2, b2, w3, b3, obs, avail, actions, old_logp, adv, nullptr, mask, rows, n_agents, n_actions,
+              eps_clip, entropy_coef, inv_denom, grads, loss, logp, entropy};
+    const int TO3 = n_actions <= 32 ? 1 : 2, IN1T = OBS + n_agents <= 32 ? 1 : 2;
+    if (TO3 == 1 && IN1T == 1) return launch_ppo<0, 1, 1>(a, (hipStream_t)stream);
+    if (TO3 == 1) return launch_ppo<0, 1, 2>(a, (hipStream_t)stream);
+    if (IN1T == 1) return launch_ppo<0, 2, 1>(a, (hipStream_t)stream);
+    return launch_ppo<0, 2, 2>(a, (hipStream_t)stream);
+}
+
+int ec_ppo_critic_grad(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                       const float* obs, const float* target, const float* mask, int64_t rows, int32_t n_agents,
+                       int32_t hidden, float inv_denom, float* grads, float* loss, float* values, void* stream) {
+    if (rows == 0) return EC_OK;
+    const void* need[] = {w1, b1, w2, b2, w3, b3, obs, mask};
+    if (int rc = check_common("ec_ppo_critic_grad", need, 8, rows, hidden, n_agents)) return rc;
+    if (grads && !target) return ec::fail(EC_EINVAL, "ec_ppo_critic_grad: grads without target");
+    PpoArgs a{w1, b1, w2, b2, w3, b3, obs, nullptr, nullptr, nullptr, nullptr, target, mask, rows, n_agents, 1,
+              0.0f, 0.0f, inv_denom, grads, loss, values, nullptr};
+    if (OBS + n_agents <= 32) return launch_ppo<1, 1, 1>(a, (hipStream_t)stream);
+    return launch_ppo<1, 1, 2>(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+"""Host side of ec_ppo_actor_grad / ec_ppo_critic_grad (include/marl_amd.h): the fused forward + loss + backward of
+the PPO actor and critic over the whole rollout batch.
+
+`FlatGrads` gives a module one flat fp32 gradient buffer in parameter order and points every `p.grad` into it, so
+that the kernel's output IS the optimizer's input and the data-parallel all-reduce is a single call on one tensor."""
+import ctypes as C
+
+import torch as th
+
+from marl_amd import _abi
+from marl_amd.utils.mlp_device import OBS_DIM, _f32, _p, _stream, linear_params
+
+
+class FlatGrads:
+    def __init__(self, module):
+        self.params = [p for p in module.parameters()]
+        n = sum(p.numel() for p in self.params)
+        self.flat = th.zeros(n, dtype=th.float32, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+
+
+def _rows(obs):
+    obs = _f32(obs, "obs").reshape(-1, OBS_DIM)
+    return obs, obs.shape[0]
+
+
+def actor_pass(actor, obs, avail, actions, mask, n_agents, old_logp=None, adv=None, eps_clip=0.2, entropy_coef=0.0,
+               inv_denom=1.0, grads=None, loss=None, want_logp=False, want_entropy=False):
+    """One launch over all rows.  Forward only when old_logp is None (returns logp / entropy); with old_logp and adv it
+    accumulates the loss into `loss` [1] and, if `grads` (flat, parameter order) is given, the gradient into it."""
+    w1, b1, w2, b2, w3, b3 = linear_params(actor)
+    obs, rows = _rows(obs)
+    dev = obs.device
+    A = w3.shape[0]
+    avail = avail.to(th.int32).contiguous().reshape(-1, A)
+    actions = actions.to(th.int64).contiguous().reshape(-1)
+    mask = _f32(mask, "mask").reshape(-1)
+    if old_logp is not None:
+        old_logp = _f32(old_logp, "old_logp").reshape(-1)
+        adv = _f32(adv, "adv").reshape(-1)
+    for t in (avail, actions, mask, old_logp, adv):
+        if t is not None and t.shape[0] != rows:
+            raise ValueError("rows mismatch")
+    logp = th.empty(rows, dtype=th.float32, device=dev) if want_logp else None
+    ent = th.empty(rows, dtype=th.float32, device=dev) if want_entropy else None
+    with th.cuda.device(dev):
+        _abi.check(_abi.lib().ec_ppo_actor_grad(_p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(obs), _p(avail),
+                                                _p(actions), _p(old_logp), _p(adv), _p(mask), rows, int(n_agents),
+                                                int(A), int(w2.shape[0]), C.c_float(eps_clip),
+                                                C.c_float(entropy_coef), C.c_float(inv_denom), _p(grads), _p(loss),
+                                                _p(logp), _p(ent), _stream(dev)), "ec_ppo_actor_grad")
+    return logp, ent
+
+
+def critic_pass(critic, obs, mask, n_agents, target=None, inv_denom=1.0, grads=None, loss=None, want_values=False):
+    w1, b1, w2, b2, w3, b3 = linear_params(critic)
+    obs, rows = _rows(obs)
+    dev = obs.device
+    mask = _f32(mask, "mask").reshape(-1)
+    if target is not None:
+        target = _f32(target, "target").reshape(-1)
+    values = th.empty(rows, dtype=th.float32, device=dev) if want_values else None
+    with th.cuda.device(dev):
+        _abi.check(_abi.lib().ec_ppo_critic_grad(_p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(obs), _p(target),
+                                                 _p(mask), rows, int(n_agents), int(w2.shape[0]),
+                                                 C.c_float(inv_denom), _p(grads), _p(loss), _p(values), _stream(dev)),
+                   "ec_ppo_critic_grad")
+    return values

@@ -1,0 +1,125 @@
+"""ec_ppo_actor_grad / ec_ppo_critic_grad against torch autograd (float64, CPU) on the losses of the reference's
+PPOAgent.train (rl/policy_gradient_rl/ppo/ppo_agent.py:76-83,123-147): loss value, per-row log-prob / entropy /
+value, and every parameter gradient.  Tolerance: 1e-4 of each gradient tensor's largest entry (fp32 accumulation over
+up to 10^5 rows in a different order, atomics), 1e-5 relative on per-row outputs."""
+import argparse
+import copy
+
+import numpy as np
+import pytest
+import torch as th
+import torch.nn.functional as F
+from torch.distributions import Categorical
+
+pytestmark = pytest.mark.gpu
+
+
+def _nets(N, seed):
+    from marl_amd.rl.policy_gradient_rl.ppo.ppo_network import Actor, Critic
+    th.manual_seed(seed)
+    ns = argparse.Namespace(obs_shape=9, n_agents=N, n_actions=N + 1, hidden_dim=64, activate_fun="relu",
+                            use_orthogonal_init=False)
+    actor, critic = Actor(ns), Critic(ns)
+    with th.no_grad():
+        for p in actor.parameters():
+            p.mul_(2.5)
+        for p in critic.parameters():
+            p.mul_(2.0)
+    return actor, critic
+
+
+def _batch(N, rows, seed):
+    g = th.Generator().manual_seed(seed)
+    A = N + 1
+    obs = th.rand(rows, 9, generator=g)
+    obs[:, 3] *= 5.0
+    avail = (th.rand(rows, A, generator=g) < 0.6).int()
+    avail[:, 0] = 1
+    avail[::7, 1:] = 0                                    # rows with a single available action (p = 1: clamp branch)
+    actions = th.multinomial(avail.float(), 1, generator=g).squeeze(-1)
+    adv = th.randn(rows, generator=g)
+    mask = (th.rand(rows, generator=g) < 0.9).float()
+    target = th.randn(rows, generator=g)
+    return obs, avail, actions, adv, mask, target
+
+
+def _torch_actor(actor, obs, ids, avail, actions, old_logp, adv, mask, eps_clip, ent_coef, denom):
+    outs = actor(th.cat([obs, ids], -1)).masked_fill(avail == 0, -1e10)
+    # Categorical(probs=softmax) in float32 semantics: clamp to float32 eps even though this reference runs in float64
+    probs = F.softmax(outs, -1)
+    probs = probs / probs.sum(-1, keepdim=True)
+    eps = th.finfo(th.float32).eps
+    logits = th.log(probs.clamp(eps, 1 - eps))
+    logp = logits.gather(-1, actions[:, None]).squeeze(-1)
+    ent = -(logits * probs).sum(-1)
+    ratio = th.exp(logp - old_logp)
+    obj = th.min(ratio * adv, th.clamp(ratio, 1 - eps_clip, 1 + eps_clip) * adv) + ent_coef * ent
+    return -(obj * mask).sum() / denom, logp, ent
+
+
+@pytest.mark.parametrize("N,rows", [(10, 1), (10, 31), (10, 33), (10, 100000), (40, 12345), (3, 5000)])
+def test_actor_loss_and_gradients(N, rows):
+    from marl_amd.utils import ppo_device
+    dev = th.device("cuda:0")
+    actor, _ = _nets(N, 3 + N)
+    obs, avail, actions, adv, mask, _ = _batch(N, rows, rows)
+    ids = th.eye(N, dtype=th.float64)[th.arange(rows) % N]
+    ref = copy.deepcopy(actor).double()
+    old = copy.deepcopy(ref)
+    with th.no_grad():
+        for p in old.parameters():
+            p.add_(0.05 * th.randn_like(p))               # behaviour policy slightly off: ratios spread around 1
+        _, old_logp, _ = _torch_actor(old, obs.double(), ids, avail, actions, th.zeros(rows, dtype=th.float64),
+                                      adv.double(), mask.double(), 0.2, 0.01, 1.0)
+    denom = float(max(mask.sum(), 1.0))
+    loss, logp, ent = _torch_actor(ref, obs.double(), ids, avail, actions, old_logp, adv.double(), mask.double(), 0.2, 0.01, denom)
+    loss.backward()
+    ratio = th.exp(logp.detach() - old_logp)
+    assert rows < 1000 or ((ratio < 0.8).any() and (ratio > 1.2).any())   # both clip sides exercised
+
+    actor = actor.to(dev)
+    fg = ppo_device.FlatGrads(actor)
+    loss_dev = th.zeros(1, device=dev)
+    lp, en = ppo_device.actor_pass(actor, obs.to(dev), avail.to(dev), actions.to(dev), mask.to(dev), N,
+                                   old_logp=old_logp.float().to(dev), adv=adv.to(dev), eps_clip=0.2, entropy_coef=0.01,
+                                   inv_denom=1.0 / denom, grads=fg.flat, loss=loss_dev, want_logp=True, want_entropy=True)
+    th.cuda.synchronize()
+    assert np.allclose(lp.cpu().double().numpy(), logp.detach().numpy(), rtol=1e-5, atol=2e-6)
+    assert np.allclose(en.cpu().double().numpy(), ent.detach().numpy(), rtol=1e-5, atol=2e-6)
+    assert abs(float(loss_dev) - float(loss)) <= 2e-5 * max(1.0, abs(float(loss)))
+    for (name, p), q in zip(actor.named_parameters(), ref.parameters()):
+        want = q.grad
+        scale = float(want.abs().max())
+        err = float((p.grad.cpu().double() - want).abs().max())
+        assert err <= 1e-4 * scale + 1e-9, (name, err, scale)
+    # forward-only mode (the no-grad evaluate_actions of ppo_agent.py:113)
+    lp2, _ = ppo_device.actor_pass(actor, obs.to(dev), avail.to(dev), actions.to(dev), mask.to(dev), N, want_logp=True)
+    assert th.equal(lp2, lp)
+
+
+@pytest.mark.parametrize("N,rows", [(10, 1), (10, 64), (10, 100000), (40, 7777)])
+def test_critic_loss_and_gradients(N, rows):
+    from marl_amd.utils import ppo_device
+    dev = th.device("cuda:0")
+    _, critic = _nets(N, 11 + N)
+    obs, _, _, _, mask, target = _batch(N, rows, rows + 1)
+    ids = th.eye(N, dtype=th.float64)[th.arange(rows) % N]
+    ref = copy.deepcopy(critic).double()
+    denom = float(max(mask.sum(), 1.0))
+    v = ref(th.cat([obs.double(), ids], -1)).squeeze(-1)
+    loss = (((v - target.double()) * mask.double()) ** 2).sum() / denom
+    loss.backward()
+    critic = critic.to(dev)
+    fg = ppo_device.FlatGrads(critic)
+    loss_dev = th.zeros(1, device=dev)
+    vals = ppo_device.critic_pass(critic, obs.to(dev), mask.to(dev), N, target=target.to(dev), inv_denom=1.0 / denom,
+                                  grads=fg.flat, loss=loss_dev, want_values=True)
+    th.cuda.synchronize()
+    assert np.allclose(vals.cpu().double().numpy(), v.detach().numpy(), rtol=1e-5, atol=2e-6)
+    assert abs(float(loss_dev) - float(loss)) <= 2e-5 * max(1.0, abs(float(loss)))
+    for (name, p), q in zip(critic.named_parameters(), ref.parameters()):
+        scale = float(q.grad.abs().max())
+        err = float((p.grad.cpu().double() - q.grad).abs().max())
+        assert err <= 1e-4 * scale + 1e-9, (name, err, scale)
+    v2 = ppo_device.critic_pass(critic, obs.to(dev), mask.to(dev), N, want_values=True)   # forward only
+    assert th.equal(v2, vals)
