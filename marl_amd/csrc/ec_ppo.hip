@@ -404,11 +404,21 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             for (int to = 0; to < T3; to++)
                 if (32 * to + (lane & 31) < A) atomicAdd(gb3p + 32 * to + (lane & 31), gb3[to]);
         } else {
+            // the 32 lanes of a half hold partial sums of the SAME 32 entries of dW3: reduce them in the wave first
+            // (one atomic per entry per wave instead of 32 colliding on two cache lines)
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) atomicAdd(gW3p + 32 * t + 8 * (r >> 2) + 4 * half + (r & 3), gW3[0][t][r]);
-            if (gb3c != 0.0f) atomicAdd(gb3p, gb3c);
+                for (int r = 0; r < 16; r++) {
+                    float v = gW3[0][t][r];
+#pragma unroll
+                    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                    if ((lane & 31) == 0) atomicAdd(gW3p + 32 * t + 8 * (r >> 2) + 4 * half + (r & 3), v);
+                }
+            float vb = gb3c;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) vb += __shfl_xor(vb, o);
+            if (lane == 0) atomicAdd(gb3p, vb);
         }
     }
 }

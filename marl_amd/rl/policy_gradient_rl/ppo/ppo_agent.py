@@ -21,7 +21,7 @@ from marl_amd.buffer.episode_buffer import EpisodeBuffer
 from marl_amd.rl.policy_gradient_rl.ppo.ppo_network import Actor, Critic
 from marl_amd.utils.action_selectors import greedy_selector, soft_selector
 from marl_amd.utils.advantage_utils import get_gae
-from marl_amd.utils import mlp_device
+from marl_amd.utils import mlp_device, ppo_device
 
 
 from marl_amd.utils.dist_utils import all_reduce_grads_, all_reduce_sum_, dist_on as _dist_on, global_mean_std  # noqa: E402,F401
@@ -49,6 +49,11 @@ class PPOAgent:
         self.buffer = EpisodeBuffer(args, device=self.device)
         self._eye = th.eye(args.n_agents, device=self.device)
         self.last_losses = {}
+        # fused HIP update: every p.grad is a view into one flat buffer that the kernels accumulate into
+        self._fg_actor = self._fg_critic = None
+        if self._fused_policy_ok() and not getattr(args, "ec_torch_update", False):
+            self._fg_actor = ppo_device.FlatGrads(self.actor)
+            self._fg_critic = ppo_device.FlatGrads(self.critic)
 
     def _with_ids(self, obs):
         ids = self._eye.expand(*obs.shape[:-2], -1, -1)
@@ -83,7 +88,52 @@ class PPOAgent:
         dist_ = Categorical(F.softmax(actor_outs, dim=-1))
         return dist_.log_prob(actions.squeeze(-1)).unsqueeze(-1), dist_.entropy().unsqueeze(-1)
 
+    def _train_fused(self):
+        """ppo_agent.py:85-134 with every network pass on the fused HIP kernels (ec_ppo_actor_grad /
+        ec_ppo_critic_grad): no autograd graph, no per-row intermediates in HBM."""
+        a = self.args
+        N = a.n_agents
+        obs, avail_actions, actions, rewards, masks, next_obs = self.buffer.sample()
+        shape = rewards.shape
+        if a.normalize_rewards:
+            mean, std = global_mean_std(rewards)
+            rewards = (rewards - mean) / (std + 1e-5)
+        old_logp, _ = ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, want_logp=True)
+        old_v = ppo_device.critic_pass(self.critic, obs, masks, N, want_values=True).view(shape)
+        old_next_v = ppo_device.critic_pass(self.critic, next_obs, masks, N, want_values=True).view(shape)
+        advantages = get_gae(a, rewards, old_v, old_next_v, masks)
+        if a.normalize_advantages:
+            mean, std = global_mean_std(advantages)
+            advantages = (advantages - mean) / (std + 1e-5)
+        targets = advantages + old_v
+        inv_denom = 1.0 / float(all_reduce_sum_(masks.sum().reshape(1).clone()))
+        losses = th.zeros(2, device=self.device)
+        for _ in range(a.epochs):
+            losses.zero_()
+            self._fg_critic.zero_()
+            ppo_device.critic_pass(self.critic, obs, masks, N, target=targets, inv_denom=inv_denom,
+                                   grads=self._fg_critic.flat, loss=losses[0:1])
+            all_reduce_sum_(self._fg_critic.flat)
+            if a.use_grad_clip:
+                th.nn.utils.clip_grad_norm_(self.critic.parameters(), a.grad_norm_clip)
+            self.critic_optimizer.step()
+            self.critic_lr_scheduler.step()
+
+            self._fg_actor.zero_()
+            ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, old_logp=old_logp, adv=advantages,
+                                  eps_clip=a.eps_clip, entropy_coef=a.entropy_coef if a.use_entropy else 0.0,
+                                  inv_denom=inv_denom, grads=self._fg_actor.flat, loss=losses[1:2])
+            all_reduce_sum_(self._fg_actor.flat)
+            if a.use_grad_clip:
+                th.nn.utils.clip_grad_norm_(self.actor.parameters(), a.grad_norm_clip)
+            self.actor_optimizer.step()
+            self.actor_lr_scheduler.step()
+        all_reduce_sum_(losses)
+        self.last_losses = {"critic_loss": losses[0].clone(), "actor_loss": losses[1].clone()}
+
     def train(self):
+        if self._fg_actor is not None:
+            return self._train_fused()
         a = self.args
         obs, avail_actions, actions, rewards, masks, next_obs = self.buffer.sample()
         obs = self._with_ids(obs)

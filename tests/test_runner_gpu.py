@@ -221,3 +221,35 @@ def test_gail_runner_iterations():
     assert int(agent.expert_transitions._written.item()) == stored and agent.update_count == 2
     runner.run(test_mode=True)
     runner.close_env()
+
+
+def test_ppo_fused_update_matches_torch_update():
+    """One PPOAgent.train() on the same rollout with the fused HIP update and with the torch-autograd update
+    (args.ec_torch_update): same losses and the same parameters after 4 epochs of Adam, to fp32 tolerance."""
+    from marl_amd.agent_register import agent_register
+    from marl_amd.runners.runner_register import runner_register
+    B = 48
+    args = _args(B, episode_limit=30, normalize_advantages=True)
+    th.manual_seed(9)
+    fused = agent_register["ppo"](args)
+    runner = runner_register["parallel"](args, fused)
+    fused.train = lambda: None          # roll out only
+    runner.run(test_mode=False)
+    del fused.train
+    args_t = _args(B, episode_limit=30, normalize_advantages=True, ec_torch_update=True)
+    plain = agent_register["ppo"](args_t)
+    assert fused._fg_actor is not None and plain._fg_actor is None
+    plain.actor.load_state_dict(fused.actor.state_dict())
+    plain.critic.load_state_dict(fused.critic.state_dict())
+    for dst, src in zip(plain.buffer.sample(), fused.buffer.sample()):
+        dst.copy_(src)
+    fused.train()
+    plain.train()
+    for k in ("critic_loss", "actor_loss"):
+        a_, b_ = float(fused.last_losses[k]), float(plain.last_losses[k])
+        assert abs(a_ - b_) <= 1e-4 * max(1.0, abs(b_)), (k, a_, b_)
+    for (n1, p1), (_, p2) in zip(list(fused.actor.named_parameters()) + list(fused.critic.named_parameters()),
+                                 list(plain.actor.named_parameters()) + list(plain.critic.named_parameters())):
+        # Adam's first steps move every weight by ~lr regardless of gradient scale: compare against the step size
+        assert float((p1 - p2).abs().max()) <= 0.05 * 4 * args.lr + 1e-6, (n1, float((p1 - p2).abs().max()))
+    runner.close_env()
