@@ -159,6 +159,7 @@ def ppo_iterations(ns, B, N, iters):
     from marl_amd.agent_register import agent_register
     from marl_amd.runners.runner_register import runner_register
     ns.n_threads, ns.algo_type, ns.obs_shape, ns.n_agents, ns.n_actions = B, "rl", 9, N, N + 1
+    ns.ec_graph_rollout = True  # one hipGraph per episode, as the env-only leg above
     th.manual_seed(100)
     agent = agent_register["ppo"](ns)
     runner = runner_register["parallel"](ns, agent)

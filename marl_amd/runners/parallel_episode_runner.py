@@ -9,6 +9,11 @@ agent's buffer.  Env e of the batch is the reference's worker e (seeds task_seed
 
 Multi-GPU: each rank constructs the runner with its own `args.ec_env_id_base` shard; episode metrics are
 summed over ranks so that `episode_info` is the whole job's.
+
+`args.ec_graph_rollout = True` captures one whole episode (reset, episode_limit x [policy, step, statistics, buffer
+insert]) in a hipGraph on first use and replays it afterwards: the rollout is launch-bound (~20 small launches per
+step), and replaying removes the host from the loop.  Kernels are warmed on a throw-away one-env instance first, so
+the captured environments' RNG streams are untouched and trajectories equal the eager ones.
 """
 import torch as th
 import torch.distributed as dist
@@ -32,8 +37,50 @@ class ParallelRunner:
         self._obs = th.empty(B, N, args.obs_shape, dtype=th.float, device=dev)
         self._avail = th.empty(B, N, args.n_actions, dtype=th.int, device=dev)
         self._totals = th.zeros(6, dtype=th.float64, device=dev)
+        self._graphs = {}
+
+    def _select(self, env, obs, avail, test_mode):
+        if self.args.algo_type == "rl":
+            return self.agent.select_actions(obs, avail, test_mode)
+        return self.agent.select_actions(env)
+
+    def _capture(self, test_mode):
+        """Warm every kernel of the episode on a one-env scratch instance, then capture the episode."""
+        args = self.args
+        scratch = type(self.env)(args, n_envs=1, env_id_base=0, device=self.env.device)
+        side = th.cuda.Stream(device=self.env.device)
+        side.wait_stream(th.cuda.current_stream(self.env.device))
+        with th.cuda.stream(side):
+            scratch.reset()
+            scratch.observe()
+            for hops in (False, True):
+                a = self._select(scratch, scratch.obs.clone(), scratch.avail.clone(), test_mode)
+                scratch.step(a, want_hops=hops)
+        th.cuda.current_stream(self.env.device).wait_stream(side)
+        th.cuda.synchronize(self.env.device)
+        scratch.close()
+        g = th.cuda.CUDAGraph()
+        with th.cuda.graph(g):
+            self._episode(test_mode)
+        return g
 
     def run(self, test_mode=False):
+        args, env = self.args, self.env
+        B = args.n_threads
+        if getattr(args, "ec_graph_rollout", False):
+            g = self._graphs.get(bool(test_mode))
+            if g is None:
+                g = self._graphs[bool(test_mode)] = self._capture(test_mode)
+            g.replay()
+            if not test_mode:
+                self.agent.buffer.t = args.episode_limit
+        else:
+            self._episode(test_mode)
+        if not test_mode:
+            self.t_env += B * args.episode_limit
+        return self._finish(test_mode)
+
+    def _episode(self, test_mode):
         args, env = self.args, self.env
         B, N = args.n_threads, args.n_agents
         self.agent.buffer.reset()
@@ -44,20 +91,20 @@ class ParallelRunner:
         for t in range(args.episode_limit):
             self._obs.copy_(env.obs)
             self._avail.copy_(env.avail)
-            if args.algo_type == "rl":
-                actions = self.agent.select_actions(self._obs, self._avail, test_mode)
-            else:
-                actions = self.agent.select_actions(env)
+            actions = self._select(env, self._obs, self._avail, test_mode)
             reward, terminated, info = env.step(actions, want_hops=(t == args.episode_limit - 1))
             # accumulate the episode statistics on device (parallel_episode_runner.py:94-99)
             self._totals[0] += reward.double().sum()
             self._totals[1] += info["task_completion_time"].double().sum()
             self._totals[2:6] += info["counters"].double().sum(0)
             if not test_mode:
-                self.t_env += B
                 rewards = reward.view(B, 1, 1).expand(B, N, 1)                     # team reward broadcast, :101
                 masks = (1 - terminated.float()).view(B, 1, 1).expand(B, N, 1)    # :102
                 self.agent.buffer.insert(self._obs, self._avail, actions.unsqueeze(-1), rewards, masks, env.obs)
+
+    def _finish(self, test_mode):
+        args, env = self.args, self.env
+        B = args.n_threads
         env.check_status()
         totals = self._totals.clone()
         n_envs = th.tensor([float(B)], dtype=th.float64, device=totals.device)

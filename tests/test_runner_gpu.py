@@ -253,3 +253,28 @@ def test_ppo_fused_update_matches_torch_update():
         # Adam's first steps move every weight by ~lr regardless of gradient scale: compare against the step size
         assert float((p1 - p2).abs().max()) <= 0.05 * 4 * args.lr + 1e-6, (n1, float((p1 - p2).abs().max()))
     runner.close_env()
+
+
+def test_graph_rollout_equals_eager_rollout():
+    """args.ec_graph_rollout: the captured-episode replay produces the same trajectories, buffer and metrics as the
+    eager loop (deterministic stub policy; env seeds identical)."""
+    from marl_amd.buffer.episode_buffer import EpisodeBuffer
+    from marl_amd.runners.runner_register import runner_register
+
+    class Agent(_FirstNeighbourAgent):
+        def __init__(self, args):
+            super().__init__()
+            self.buffer = EpisodeBuffer(args, device="cuda")
+
+    infos, bufs = [], []
+    for graph in (False, True):
+        args = _args(40, ec_env_id_base=5, episode_limit=30, ec_graph_rollout=graph)
+        agent = Agent(args)
+        runner = runner_register["parallel"](args, agent)
+        infos.append([runner.run(test_mode=False) for _ in range(3)])
+        assert runner.t_env == 3 * 40 * 30 and agent.trained == 3 and agent.buffer.can_sample()
+        bufs.append([t.clone() for t in agent.buffer.sample()])
+        runner.close_env()
+    assert infos[0] == infos[1]
+    for a, b in zip(*bufs):
+        assert th.equal(a, b)
