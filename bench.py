@@ -98,6 +98,19 @@ def algorithmic_bytes_per_env_step(N, live, draws):
     return io + 2 * 16 * N + 2 * 40 * live + 16 * draws
 
 
+def recorded_traffic():
+    """HBM bytes per k_step launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc runs of
+    tools/prof_step.py for FETCH_SIZE and WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes; bench.py cannot
+    run under the profiler itself).  None when no such record exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_k_step.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        rec = json.load(f)
+    return rec.get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+
+
 def measure_roofline(env, roll, n_steps):
     """Average ec_step kernel duration from HIP events recorded on the launch stream around each launch,
     plus the measured L-bar (live tasks/env) and D-bar (MT19937 doubles/env-step) of the same steps."""
@@ -251,8 +264,10 @@ def main():
         avg_ms, med_ms, lbar, draws = measure_roofline(env, roll, a.roofline_steps)
         bytes_step = algorithmic_bytes_per_env_step(N, lbar, draws) * B
         achieved = bytes_step / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = recorded_traffic() if (B == 4096 and N == 10) else (None, None)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_step",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                           "kernel": "k_step",
                            "kernel_avg_us": avg_ms * 1e3, "kernel_median_us": med_ms * 1e3,
                            "algorithmic_bytes_per_launch": bytes_step, "live_tasks_per_env": lbar,
                            "rng_doubles_per_env_step": draws}
