@@ -48,6 +48,8 @@ _HIP_FLAGS = (
     ("ec_max_ticks", int, 0),
     ("ec_hop_hist_len", int, 32),
     ("ec_env_id_base", int, 0),  # first env id of this rank's shard (seeds are task_seed + env id + node)
+    ("ec_graph_rollout", int, 0),  # 1: ParallelRunner replays one hipGraph per episode
+    ("ec_torch_update", int, 0),   # 1: PPOAgent.train keeps the torch-autograd update instead of the fused kernels
 )
 
 
