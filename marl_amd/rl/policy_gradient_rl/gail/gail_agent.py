@@ -20,7 +20,7 @@ from torch.optim import Adam
 from marl_amd.buffer.expert_transitions import ExpertTransitions
 from marl_amd.buffer.ppo_expert_buffer import PPOExpertBuffer
 from marl_amd.rl.policy_gradient_rl.gail.gail_network import Actor, Critic, Discriminator
-from marl_amd.utils import mlp_device
+from marl_amd.utils import mlp_device, ppo_device
 from marl_amd.utils.action_selectors import greedy_selector, soft_selector
 from marl_amd.utils.advantage_utils import get_gae
 from marl_amd.utils.dist_utils import (all_reduce_grads_, all_reduce_sum_, broadcast_params_, global_mean_std,
@@ -49,6 +49,11 @@ class GAILAgent:
         self.performance_history = []
         self._eye = th.eye(args.n_agents, device=self.device)
         self.last_losses = {}
+        # fused HIP update of actor / critic (see PPOAgent): p.grad views one flat buffer per network
+        self._fg_actor = self._fg_critic = None
+        if self._fused_ok() and not getattr(args, "ec_torch_update", False):
+            self._fg_actor = ppo_device.FlatGrads(self.actor)
+            self._fg_critic = ppo_device.FlatGrads(self.critic)
 
     # ------------------------------------------------------------------ acting
     def _with_ids(self, obs):
@@ -138,13 +143,59 @@ class GAILAgent:
         self.last_losses["discriminator_loss"] = loss.detach()
         return rewards
 
+    def _train_fused(self, obs, avail_actions, actions, rewards, masks, next_obs):
+        """gail_agent.py:182-226 with the actor / critic passes on ec_ppo_actor_grad / ec_ppo_critic_grad; the BC term
+        (64 expert transitions) is back-propagated by autograd INTO the same flat gradient buffer."""
+        a = self.args
+        N = a.n_agents
+        shape = rewards.shape
+        if a.normalize_rewards:
+            mean, std = global_mean_std(rewards)
+            rewards = (rewards - mean) / (std + 1e-8)
+        old_logp, _ = ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, want_logp=True)
+        old_v = ppo_device.critic_pass(self.critic, obs, masks, N, want_values=True).view(shape)
+        old_next_v = ppo_device.critic_pass(self.critic, next_obs, masks, N, want_values=True).view(shape)
+        advantages = get_gae(a, rewards, old_v, old_next_v, masks)
+        if a.normalize_advantages:
+            mean, std = global_mean_std(advantages)
+            advantages = (advantages - mean) / (std + 1e-8)
+        targets = advantages + old_v
+        inv_denom = 1.0 / float(all_reduce_sum_(masks.sum().reshape(1).clone()))
+        self.update_bc_weight()
+        losses = th.zeros(2, device=self.device)
+        for _ in range(a.epochs):
+            losses.zero_()
+            self._fg_critic.zero_()
+            ppo_device.critic_pass(self.critic, obs, masks, N, target=targets, inv_denom=inv_denom,
+                                   grads=self._fg_critic.flat, loss=losses[0:1])
+            all_reduce_sum_(self._fg_critic.flat)
+            if a.use_grad_clip:
+                th.nn.utils.clip_grad_norm_(self.critic.parameters(), a.grad_norm_clip)
+            self.critic_optimizer.step()
+
+            self._fg_actor.zero_()
+            ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, old_logp=old_logp, adv=advantages,
+                                  eps_clip=a.eps_clip, entropy_coef=a.entropy_coef if a.use_entropy else 0.0,
+                                  inv_denom=inv_denom, grads=self._fg_actor.flat, loss=losses[1:2])
+            (self.bc_loss_weight * self.compute_bc_loss() / world_size()).backward()
+            all_reduce_sum_(self._fg_actor.flat)
+            if a.use_grad_clip:
+                th.nn.utils.clip_grad_norm_(self.actor.parameters(), a.grad_norm_clip)
+            self.actor_optimizer.step()
+        all_reduce_sum_(losses)
+        self.update_count += 1
+        self.last_losses.update({"critic_loss": losses[0].clone(), "actor_loss": losses[1].clone()})
+
     def train(self):
         a = self.args
         obs, avail_actions, actions, rewards, masks, next_obs = self.buffer.sample()
         obs_id = self._with_ids(obs)
-        next_obs_id = self._with_ids(next_obs)
         if len(self.expert_transitions) >= 10:
             rewards = self._discriminator_step(obs_id, actions)
+        if self._fg_actor is not None:
+            del obs_id
+            return self._train_fused(obs, avail_actions, actions, rewards, masks, next_obs)
+        next_obs_id = self._with_ids(next_obs)
         if a.normalize_rewards:
             mean, std = global_mean_std(rewards)
             rewards = (rewards - mean) / (std + 1e-8)

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Wall time of one GAIL / DGAIL iteration (expert-guided rollout + agent.train) on the batched device path
+(BASELINE.json configs[3]/[4] shapes).  Prints one JSON object per run.
+
+    python tools/bench_imitation.py --algo dgail --envs 1024 [--nodes 10] [--iters 3] [--diffusion-reward]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--algo", default="dgail", choices=["gail", "dgail"])
+    ap.add_argument("--envs", type=int, default=1024)
+    ap.add_argument("--nodes", type=int, default=10)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--diffusion-reward", action="store_true", help="DGAIL: use_simplified_reward=False")
+    a = ap.parse_args()
+    import torch as th
+    from marl_amd.agent_register import agent_config_register, agent_register
+    from marl_amd.default_config import add_default_args
+    from marl_amd.envs.edge_computing.multihop.edge_computing_config import add_edge_computing_env_args
+    from marl_amd.runners.runner_register import runner_register
+    p = argparse.ArgumentParser(conflict_handler="resolve")
+    p = agent_config_register[a.algo](add_edge_computing_env_args(add_default_args(p)))
+    ns = p.parse_args(["--task_size_max=6000", "--edge_node_num=%d" % a.nodes])
+    ns.n_threads, ns.obs_shape, ns.n_agents, ns.n_actions = a.envs, 9, a.nodes, a.nodes + 1
+    ns.state_shape, ns.device = 9 * a.nodes, "cuda"
+    if a.diffusion_reward:
+        ns.use_simplified_reward = False
+    th.manual_seed(100)
+    agent = agent_register[a.algo](ns)
+    runner = runner_register[ns.runner](ns, agent)
+    spans, tot = [], []
+    train = agent.train
+
+    def timed(*args, **kw):
+        th.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = train(*args, **kw)
+        th.cuda.synchronize()
+        spans.append(time.perf_counter() - t0)
+        return r
+
+    agent.train = timed
+    info = None
+    for _ in range(a.iters + 1):
+        th.cuda.synchronize()
+        t0 = time.perf_counter()
+        info = runner.run(test_mode=False)
+        th.cuda.synchronize()
+        tot.append(time.perf_counter() - t0)
+    med = lambda v: sorted(v)[len(v) // 2]
+    T = ns.episode_limit
+    out = {"algo": a.algo, "envs": a.envs, "agents": a.nodes, "episode_limit": T, "rows_per_update": a.envs * T * a.nodes,
+           "reward": "diffusion" if a.diffusion_reward else "default", "iteration_ms": 1e3 * med(tot[1:]),
+           "train_ms": 1e3 * med(spans[1:]) if len(spans) > 1 else None,
+           "rollout_ms": 1e3 * (med(tot[1:]) - (med(spans[1:]) if len(spans) > 1 else 0.0)),
+           "first_iteration_ms": 1e3 * tot[0], "success_rate": info["success_rate"],
+           "expert_buffer": len(agent.expert_transitions)}
+    print(json.dumps(out), flush=True)
+    runner.close_env()
+
+
+if __name__ == "__main__":
+    main()
