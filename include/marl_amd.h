@@ -185,6 +185,23 @@ int ec_diffusion_reward(const float* w1, const float* b1, const float* w2, const
                         int32_t hidden, float r1_lambda, float* loss_expert, float* loss_agent, float* d_phi,
                         float* reward, void* stream);
 
+/* --- rollout bookkeeping ----------------------------------------------------------------------------------------
+ * One launch per env step instead of ~20 torch launches: replaces EpisodeBuffer.insert (buffer/episode_buffer.py:21-28)
+ * with the team-reward broadcast and mask = 1 - terminated of parallel_episode_runner.py:101-102, and the running
+ * episode statistics of :94-99 (same pattern in gail_runner.py:59-95, dgail_runner.py:66-91).
+ *   obs / avail: the env's observation AFTER step t (ec_step's next_obs / next_avail); it is stored as next_obs[:, t]
+ *                and, when t + 1 < episode_limit, as obs[:, t+1] / avail_actions[:, t+1].  t = -1 stores the initial
+ *                observation as obs[:, 0] / avail_actions[:, 0] and touches nothing else.
+ *   actions [B,N] i64 is what the buffer keeps for step t (the agent's action, also under expert guidance).
+ *   buf_*: the [B,T,N,.] tensors of the buffer (all NULL: statistics only, test mode).
+ *   totals f64[6] += {sum reward, sum completion time, finish, success, drop, failure} over the batch, summed in a
+ *   fixed order (deterministic). */
+int ec_store_transition(const float* obs, const int32_t* avail, const int64_t* actions, const float* reward,
+                        const uint8_t* terminated, const int32_t* counters, const float* completion_time,
+                        int64_t n_envs, int32_t n_agents, int32_t obs_dim, int32_t n_actions, int64_t t,
+                        int64_t episode_limit, float* buf_obs, int32_t* buf_avail, int64_t* buf_actions,
+                        float* buf_rewards, float* buf_masks, float* buf_next_obs, double* totals, void* stream);
+
 /* --- fused PPO loss + gradients ----------------------------------------------------------------------------------
  * One launch per network does the forward pass, the loss and the whole backward pass of the (obs | one-hot agent id)
  * -> 64 -> 64 -> {n_actions, 1} MLP over `rows` = B*T*n_agents rows (row r is agent r % n_agents) and ACCUMULATES

@@ -11,6 +11,7 @@ import torch as th
 import torch.distributed as dist
 
 from marl_amd.envs.env_register import env_register
+from marl_amd.runners._transition_store import TransitionStore
 from marl_amd.utils.dist_utils import dist_on
 
 
@@ -30,6 +31,7 @@ class DGAILRunner:
         self._avail = th.empty(B, N, args.n_actions, dtype=th.int, device=dev)
         self._totals = th.zeros(6, dtype=th.float64, device=dev)
         self.expert_steps = 0  # expert-driven env steps of the last episode
+        self._store = TransitionStore(self.env, self._totals)
 
     def _expert_ratio(self):
         """dgail_runner.py:30-38"""
@@ -56,28 +58,40 @@ class DGAILRunner:
         self._totals.zero_()
         n_expert = th.zeros((), dtype=th.int64, device=env.device)
         steps = 0
+        fast = self._store.usable(self.agent.buffer)
+        buf = None if test_mode else self.agent.buffer
+        if fast and buf is not None:
+            self._store.initial(buf)
         for t in range(args.episode_limit):
-            self._obs.copy_(env.obs)
-            self._avail.copy_(env.avail)
+            if fast:
+                obs, avail = env.obs, env.avail          # read in place; ec_step replaces them with the next observation
+            else:
+                self._obs.copy_(env.obs)
+                self._avail.copy_(env.avail)
+                obs, avail = self._obs, self._avail
             use_expert = self._use_expert(test_mode)
-            agent_actions = self.agent.select_actions(self._obs, self._avail, test_mode)
+            agent_actions = self.agent.select_actions(obs, avail, test_mode)
             if use_expert is not None:
                 expert_actions = self.agent.get_expert_actions(env)
                 exec_actions = th.where(use_expert.unsqueeze(-1), expert_actions, agent_actions)
                 n_expert += use_expert.sum()
+                self.agent.store_expert_data(obs, expert_actions, use_expert)     # :93-94 (before the step: obs is pre-step)
             else:
                 exec_actions = agent_actions
             reward, terminated, info = env.step(exec_actions, want_hops=(t == args.episode_limit - 1))
             steps += 1
+            if not test_mode:
+                self.t_env += B
+            if fast:
+                self._store.step(t, agent_actions, reward, terminated, info, buf)   # the buffer keeps the AGENT's action, :81
+                continue
             self._totals[0] += reward.double().sum()
             self._totals[1] += info["task_completion_time"].double().sum()
             self._totals[2:6] += info["counters"].double().sum(0)
             if not test_mode:
-                self.t_env += B
                 rewards = reward.view(B, 1, 1).expand(B, N, 1)
                 masks = (1 - terminated.float()).view(B, 1, 1).expand(B, N, 1)
-                self.agent.buffer.insert(self._obs, self._avail, agent_actions.unsqueeze(-1), rewards, masks, env.obs)
-                self.agent.store_expert_data(self._obs, expert_actions, use_expert)
+                self.agent.buffer.insert(obs, avail, agent_actions.unsqueeze(-1), rewards, masks, env.obs)
         env.check_status()
         totals = self._totals.clone()
         n_envs = th.tensor([float(B)], dtype=th.float64, device=totals.device)

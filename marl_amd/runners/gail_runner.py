@@ -7,6 +7,7 @@ import torch as th
 import torch.distributed as dist
 
 from marl_amd.envs.env_register import env_register
+from marl_amd.runners._transition_store import TransitionStore
 from marl_amd.utils.dist_utils import dist_on
 
 
@@ -22,6 +23,7 @@ class GAILRunner:
         self._obs = th.empty(B, N, args.obs_shape, dtype=th.float, device=dev)
         self._avail = th.empty(B, N, args.n_actions, dtype=th.int, device=dev)
         self._totals = th.zeros(6, dtype=th.float64, device=dev)
+        self._store = TransitionStore(self.env, self._totals)
 
     def run(self, test_mode=False, t_expert=0):
         args, env = self.args, self.env
@@ -31,28 +33,38 @@ class GAILRunner:
         env.observe()
         self._totals.zero_()
         guided = (not test_mode) and t_expert < args.expert_guidance_steps
+        fast = self._store.usable(self.agent.buffer)
+        buf = None if test_mode else self.agent.buffer
+        if fast and buf is not None:
+            self._store.initial(buf)
         for t in range(args.episode_limit):
-            self._obs.copy_(env.obs)
-            self._avail.copy_(env.avail)
-            agent_actions = self.agent.select_actions(self._obs, self._avail, test_mode)
-            use_expert = None
+            if fast:
+                obs, avail = env.obs, env.avail          # read in place; ec_step replaces them with the next observation
+            else:
+                self._obs.copy_(env.obs)
+                self._avail.copy_(env.avail)
+                obs, avail = self._obs, self._avail
+            agent_actions = self.agent.select_actions(obs, avail, test_mode)
             if guided:
                 use_expert = th.rand(B, device=env.device) < self.agent.get_expert_ratio(t_expert)
                 expert_actions = self.agent.get_expert_actions(env)
                 exec_actions = th.where(use_expert.unsqueeze(-1), expert_actions, agent_actions)
+                self.agent.store_expert_data(obs, expert_actions, use_expert)     # :97-98 (obs is the pre-step one)
             else:
                 exec_actions = agent_actions
             reward, terminated, info = env.step(exec_actions, want_hops=(t == args.episode_limit - 1))
+            if not test_mode:
+                self.t_env += B
+            if fast:
+                self._store.step(t, agent_actions, reward, terminated, info, buf)
+                continue
             self._totals[0] += reward.double().sum()
             self._totals[1] += info["task_completion_time"].double().sum()
             self._totals[2:6] += info["counters"].double().sum(0)
             if not test_mode:
-                self.t_env += B
                 rewards = reward.view(B, 1, 1).expand(B, N, 1)
                 masks = (1 - terminated.float()).view(B, 1, 1).expand(B, N, 1)
-                self.agent.buffer.insert(self._obs, self._avail, agent_actions.unsqueeze(-1), rewards, masks, env.obs)
-                if use_expert is not None:
-                    self.agent.store_expert_data(self._obs, expert_actions, use_expert)
+                self.agent.buffer.insert(obs, avail, agent_actions.unsqueeze(-1), rewards, masks, env.obs)
         env.check_status()
         totals = self._totals.clone()
         n_envs = th.tensor([float(B)], dtype=th.float64, device=totals.device)

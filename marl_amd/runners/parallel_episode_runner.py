@@ -19,6 +19,7 @@ import torch as th
 import torch.distributed as dist
 
 from marl_amd.envs.env_register import env_register
+from marl_amd.runners._transition_store import TransitionStore
 
 
 def _dist_on():
@@ -38,6 +39,7 @@ class ParallelRunner:
         self._avail = th.empty(B, N, args.n_actions, dtype=th.int, device=dev)
         self._totals = th.zeros(6, dtype=th.float64, device=dev)
         self._graphs = {}
+        self._store = TransitionStore(self.env, self._totals)
 
     def _select(self, env, obs, avail, test_mode):
         if self.args.algo_type == "rl":
@@ -87,8 +89,19 @@ class ParallelRunner:
         env.reset()
         env.observe()
         self._totals.zero_()
+        fast = self._store.usable(self.agent.buffer)
+        buf = None if test_mode else self.agent.buffer
+        if fast and buf is not None:
+            self._store.initial(buf)
         # all environments of the batch terminate together at episode_limit (edge_computing_env.py:139-142)
         for t in range(args.episode_limit):
+            if fast:
+                # the policy reads the env's observation in place; ec_step overwrites it with the next one, which
+                # one launch then files as next_obs[t] / obs[t+1] together with the rest of the transition
+                actions = self._select(env, env.obs, env.avail, test_mode)
+                reward, terminated, info = env.step(actions, want_hops=(t == args.episode_limit - 1))
+                self._store.step(t, actions, reward, terminated, info, buf)
+                continue
             self._obs.copy_(env.obs)
             self._avail.copy_(env.avail)
             actions = self._select(env, self._obs, self._avail, test_mode)
