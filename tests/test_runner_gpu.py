@@ -315,3 +315,23 @@ def test_gail_fused_update_matches_torch_update():
     for (n1, p1), (_, p2) in zip(list(fused.actor.named_parameters()) + list(fused.critic.named_parameters()),
                                  list(plain.actor.named_parameters()) + list(plain.critic.named_parameters())):
         assert float((p1 - p2).abs().max()) <= 0.05 * 4 * a1.lr + 1e-6, (n1, float((p1 - p2).abs().max()))
+
+
+def test_main_driver_trains_tests_and_checkpoints(tmp_path, monkeypatch):
+    """python -m marl_amd.main --name=ppo ... : train loop with periodic evaluation (utils/run_utils.py:15-140),
+    scalar tags, checkpoint files under results/models/<folder>/<run>/ that load back."""
+    import json
+    from marl_amd import main as driver
+    monkeypatch.chdir(tmp_path)
+    argv = ["--name=ppo", "--task_size_max=6000", "--seed=100", "--runner=parallel", "--n_threads=16", "--episode_limit=20",
+            "--t_max=900", "--test_interval=320", "--test_nepisode=32", "--folder=t", "--log_tag=unit"]
+    out = driver.main(argv)
+    assert out["episodes"] == 3                       # t_env 320, 640, 960 > t_max
+    run_dir = tmp_path / "results" / "models" / "t" / out["run"]
+    assert (run_dir / "actor.th").exists() and (run_dir / "critic.th").exists()
+    tags = {json.loads(l)["tag"] for l in open(tmp_path / "results" / "tensorboard" / "t" / out["run"] / "scalars.jsonl")}
+    assert {"Training/Episode_Reward", "Training/Cumulative_Avg_Reward", "Training/Moving_Avg_Reward_100",
+            "success_rate_avg", "success_rate_std", "Test/Episode_Return_Avg"} <= tags
+    res = driver.main(["--name=ppo", "--task_size_max=6000", "--n_threads=16", "--episode_limit=20", "--test_nepisode=32",
+                       "--test_models=1", "--load_models=1", "--folder=t", "--checkpoint_path=" + out["run"]])
+    assert 0.0 <= res["success_rate"] <= 1.0 and abs(res["success_rate"] + res["drop_rate"] + res["failure_rate"] - 1) < 1e-9
