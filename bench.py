@@ -3,9 +3,9 @@
 
 Workload (BASELINE.json configs[1]): the batched edge_computing environment, 4096 envs x 10 agents per
 GPU, task_size_max=6000, uniform-random policy over the availability mask.  One "step" = one pass of
-the rollout hot path over the whole batch: random-policy kernel -> ec_step (offload, 10 mini-slots of
-execute/receive, statistics, generate_task) with the next observation + availability mask fused into the
-same launch; every episode_limit steps the envs are reset as ParallelRunner does.  Inputs and all state
+the rollout hot path over the whole batch: ec_step (offload, 10 mini-slots of execute/receive, statistics,
+generate_task) with the next observation + availability mask and the random policy's draw for the next step
+fused into the same launch; every episode_limit steps the envs are reset as ParallelRunner does.  Inputs and all state
 are resident in HBM; nothing crosses PCIe inside the timed region.
 
     python bench.py --gpus 1 --steps 1000 --warmup 200
@@ -68,15 +68,14 @@ class Rollout:
             with th.cuda.graph(self.graph):
                 self._episode(self.T)
 
-    def _one_step(self):
-        self.env.random_actions(seed=0, counter=0, out=self.actions, counter_dev=self.counter_dev)
-        self.env.step(self.actions, fuse_observe=True)
-
     def _episode(self, n):
+        # the first actions of an episode come from the policy kernel; every step then draws the next step's actions
+        # from the mask it has just produced, in the same launch (ec_step_random_policy), in place
         self.env.reset()
         self.env.observe()
+        self.env.random_actions(seed=0, counter=0, out=self.actions, counter_dev=self.counter_dev)
         for _ in range(n):
-            self._one_step()
+            self.env.step_random_policy(self.actions, seed=0)
 
     def run(self, n_steps):
         """Run exactly n_steps env steps (whole episodes first, then a partial one)."""
@@ -125,10 +124,11 @@ def measure_roofline(env, roll, n_steps):
         if t and t % env.episode_limit == 0:
             env.reset()
             env.observe()
-        env.random_actions(seed=0, counter=0, out=roll.actions, counter_dev=roll.counter_dev)
+        if t % env.episode_limit == 0:
+            env.random_actions(seed=0, counter=0, out=roll.actions, counter_dev=roll.counter_dev)
         a, b = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
         a.record()
-        env.step(roll.actions, fuse_observe=True)
+        env.step_random_policy(roll.actions, seed=0)
         b.record()
         pairs.append((a, b))
         if t % 10 == 5:

@@ -115,6 +115,16 @@ int ec_step(ec_handle h, const int64_t* actions, float* reward, uint8_t* termina
 int ec_random_policy(const int32_t* avail, int64_t rows, int32_t n_actions, uint64_t seed, uint64_t counter,
                      uint64_t* counter_dev, int64_t* actions, void* stream);
 
+/* ec_step followed, in the same launch, by the uniform-random policy on the availability mask of the NEW state
+ * (requires next_avail): next_actions [B,N] i64 receives exactly what
+ *   ec_random_policy(next_avail, B*N, N+1, seed, counter + s, NULL, next_actions, stream)
+ * would write, where s is the number of steps this handle has taken since ec_create, this one included (a device-side
+ * launch counter without atomics: all envs of a handle step together).  next_actions may alias actions (each lane
+ * reads its action before it writes the next one).  The env-only benchmark loop (BASELINE config 2). */
+int ec_step_random_policy(ec_handle h, const int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
+                          float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail,
+                          uint64_t seed, uint64_t counter, int64_t* next_actions, void* stream);
+
 /* The expert of the GAIL / DGAIL runners for every env of the handle: OptimalAgent.get_current_optimal_action
  * (optimal/optimal_agent.py:102-120) = _conservative_action_selection at conservativeness 1.0 (:166-209) with the
  * reliability / time-margin / load / efficiency scores of :211-375, evaluated on the device state instead of walking

@@ -154,6 +154,7 @@ struct EcDev {
     // per-env state
     u32* cur_step;  // [B]
     u32* tick;      // [B] execute/receive call index
+    u32* total_steps;  // [B] steps taken since creation (never reset; feeds the fused random policy's counter)
     int32_t* hop_hist;  // [B][H]
     u32* status;    // [1]
     u64* stamps;    // [blocks][16] phase time stamps (EC_STAMPS diagnostic build only), else null
@@ -601,6 +602,7 @@ __global__ void k_seed(EcDev d, u32 task_seed0, u32 fail_seed0) {
     if (node == 0) {
         d.cur_step[env] = 0;
         d.tick[env] = 0;
+        d.total_steps[env] = 0;
         for (int h = 0; h < d.H; h++) d.hop_hist[env * d.H + h] = 0;
     }
 }
@@ -778,6 +780,20 @@ __host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int
 
 constexpr u32 KIND_SUCCESS = 1u << 16;
 
+// optional tail of the step: the uniform-random policy of ec_random_policy for the NEXT step, drawn from the
+// availability mask the fused observation has just produced (same generator, same row numbering)
+struct StepPolicy {
+    u64 seed, counter;       // the draw uses counter + (steps this handle has taken, this one included)
+    int64_t* next_actions;   // [B,N] or null (no policy)
+};
+
+__device__ __forceinline__ u64 policy_hash(u64 seed, u64 counter, u64 rows, u64 r) {
+    u64 z = seed + 0x9E3779B97F4A7C15ull * (counter * rows + r + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 #ifdef EC_STAMPS
 #define EC_STAMP(i)                                                                           \
     do {                                                                                      \
@@ -797,7 +813,7 @@ template <int KMAX, int DMAX>
 __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict__ actions, float* __restrict__ reward,
                                               uint8_t* __restrict__ terminated, int32_t* __restrict__ counters,
                                               float* __restrict__ completion_time, float* __restrict__ next_obs,
-                                              int32_t* __restrict__ next_avail) {
+                                              int32_t* __restrict__ next_avail, StepPolicy pol) {
     static_assert(RB_FAIL >= KMAX + DMAX, "failure window too small");
     static_assert(RB_FAIL * 4 >= 12 + 36, "observation scratch does not fit the failure window");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -874,8 +890,10 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         lkA[s] = 0xffffffffu;
         lkB[s] = 0;
     }
+    u32 steps_before = 0;
     if (L.valid) {
         c0 = d.tick[L.env];
+        steps_before = d.total_steps[L.env];
         has_new = d.has_new[lane];
         n_off = d.n_off[lane];
         action = actions[lane];
@@ -1276,6 +1294,7 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         }
         const u32 step_now = d.cur_step[L.env] + 1;  // :125
         d.cur_step[L.env] = step_now;
+        d.total_steps[L.env] = steps_before + 1;
         d.tick[L.env] = c0 + (u32)d.S;
         if (reward) reward[L.env] = (float)r;
         if (completion_time) completion_time[L.env] = (float)t;
@@ -1368,11 +1387,50 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         u32* s_any = s_hasnew + NT;
         float* s_obs = reinterpret_cast<float*>(s_any + NT);
         observe_block(d, L, wq_len, wait_sum, has_new, newt, next_obs, next_avail, s_full, s_hasnew, s_any, s_obs);
+        if (pol.next_actions) {
+            // s_full / s_hasnew / s_any still hold the mask's ingredients (edge_node.py:179-197)
+            // every env of the handle has taken the same number of steps: a launch counter without atomics
+            const u64 counter = pol.counter + (u64)steps_before + 1;
+            if (L.valid) {
+                int act = N;  // no task: idle is the only available action
+                if (has_new) {
+                    const u32* full = s_full + L.env_local * N;
+                    const u64 z = policy_hash(pol.seed, counter, (u64)P, (u64)lane);
+                    if (d.adj_bits) {
+                        // the mask as bits: neighbours and self with room, else self (edge_node.py:179-197)
+                        u64 fullbits = 0;
+                        for (int j = 0; j < N; j++) fullbits |= (u64)(full[j] != 0) << j;
+                        u64 m = d.adj_bits[node] & ~fullbits;
+                        if (!m) m = 1ull << node;
+                        const int cnt = __popcll(m);
+                        int pick = (int)(((z >> 32) * (u64)cnt) >> 32);
+                        while (pick-- > 0) m &= m - 1;  // drop the `pick` lowest set bits
+                        act = __ffsll((unsigned long long)m) - 1;
+                    } else {
+                        const bool any = s_any[tid] != 0;
+                        int cnt = 0;
+                        for (int j = 0; j < N; j++) cnt += ((d.adj[node * d.A + j] && !full[j]) || (!any && j == node)) ? 1 : 0;
+                        int pick = cnt > 0 ? (int)(((z >> 32) * (u64)cnt) >> 32) : 0;
+                        act = d.A - 1;
+                        for (int j = 0; j < N; j++) {
+                            if ((d.adj[node * d.A + j] && !full[j]) || (!any && j == node)) {
+                                if (pick == 0) {
+                                    act = j;
+                                    break;
+                                }
+                                pick--;
+                            }
+                        }
+                    }
+                }
+                pol.next_actions[lane] = act;
+            }
+        }
     }
     EC_STAMP(8);
 }
 
-typedef void (*step_fn)(EcDev, const int64_t*, float*, uint8_t*, int32_t*, float*, float*, int32_t*);
+typedef void (*step_fn)(EcDev, const int64_t*, float*, uint8_t*, int32_t*, float*, float*, int32_t*, StepPolicy);
 template <int KMAX>
 step_fn pick_step_d(int D) {
     if (D <= 4) return k_step<KMAX, 4>;
@@ -1782,6 +1840,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     EC_TRY(dev_alloc(h, &d.n_off, P));
     EC_TRY(dev_alloc(h, &d.cur_step, (size_t)B));
     EC_TRY(dev_alloc(h, &d.tick, (size_t)B));
+    EC_TRY(dev_alloc(h, &d.total_steps, (size_t)B));
     EC_TRY(dev_alloc(h, &d.hop_hist, (size_t)B * d.H));
     EC_TRY(dev_alloc(h, &d.status, 1, true));
     d.stamps = nullptr;
@@ -1898,11 +1957,12 @@ int ec_observe(ec_handle h, float* obs, int32_t* avail, void* stream) {
     return EC_OK;
 }
 
-int ec_step(ec_handle h, const int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
-            float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail, void* stream) {
+static int step_impl(ec_handle h, const int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
+                     float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail, StepPolicy pol,
+                     void* stream) {
     if (!h || !actions) return ec::fail(EC_EINVAL, "null handle or actions");
     hipLaunchKernelGGL(h->step, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_step, (hipStream_t)stream, h->d,
-                       actions, reward, terminated, counters, completion_time, next_obs, next_avail);
+                       actions, reward, terminated, counters, completion_time, next_obs, next_avail, pol);
     if (hop_hist) {
         const int64_t n = h->d.B * h->d.H;
         hipLaunchKernelGGL(k_copy_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -1910,6 +1970,21 @@ int ec_step(ec_handle h, const int64_t* actions, float* reward, uint8_t* termina
     }
     EC_HIP(hipGetLastError());
     return EC_OK;
+}
+
+int ec_step(ec_handle h, const int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
+            float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail, void* stream) {
+    return step_impl(h, actions, reward, terminated, counters, completion_time, hop_hist, next_obs, next_avail,
+                     StepPolicy{0, 0, nullptr}, stream);
+}
+
+int ec_step_random_policy(ec_handle h, const int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
+                          float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail,
+                          uint64_t seed, uint64_t counter, int64_t* next_actions, void* stream) {
+    if (!next_actions) return ec::fail(EC_EINVAL, "ec_step_random_policy: null next_actions");
+    if (!next_avail) return ec::fail(EC_EINVAL, "ec_step_random_policy needs the fused observation (next_avail)");
+    return step_impl(h, actions, reward, terminated, counters, completion_time, hop_hist, next_obs, next_avail,
+                     StepPolicy{seed, counter, next_actions}, stream);
 }
 
 int ec_random_policy(const int32_t* avail, int64_t rows, int32_t n_actions, uint64_t seed, uint64_t counter,

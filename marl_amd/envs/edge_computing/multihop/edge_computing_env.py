@@ -105,6 +105,24 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
             self.observe()
         return self.avail
 
+    def step_random_policy(self, actions, seed, counter=0, next_actions=None, want_hops=False):
+        """step() + the uniform-random policy for the next step in the same launch (ec_step_random_policy): the draw
+        equals random_actions(seed, counter + steps taken by this env object so far, this one included).
+        next_actions defaults to `actions` itself (in place).  Returns (reward, terminated, info, next_actions)."""
+        if actions.dtype != th.int64 or not actions.is_contiguous() or actions.device != self.device:
+            raise ValueError("actions must be a contiguous int64 tensor on the env's device")
+        nxt = actions if next_actions is None else next_actions
+        _abi.check(self.lib.ec_step_random_policy(self._h, _ptr(actions), _ptr(self.reward), _ptr(self.terminated),
+                                                  _ptr(self.counters), _ptr(self.completion_time),
+                                                  _ptr(self.hop_hist) if want_hops else None, _ptr(self.obs),
+                                                  _ptr(self.avail), int(seed), int(counter), _ptr(nxt),
+                                                  self._stream()), "ec_step_random_policy")
+        self._obs_valid = True
+        info = {"counters": self.counters, "task_completion_time": self.completion_time}
+        if want_hops:
+            info["hop_hist"] = self.hop_hist
+        return self.reward, self.terminated, info, nxt
+
     def step(self, actions, want_hops=False, fuse_observe=True):
         """actions: int64 [B,N] device tensor.  Returns (reward[B] f32, terminated[B] u8, info) where info holds
         device tensors: the four counters of edge_computing_env.py:130-135 as columns of `counters`,

@@ -258,3 +258,33 @@ def test_expert_policy_lockstep_batch(oracle_lib):
         assert np.array_equal(info["counters"].cpu().numpy(), out["counters"]), (t, "counters")
     assert n_remote > 1000
     env.close()
+
+
+@pytest.mark.parametrize("name,B", [("env10", 300), ("env40", 40)])
+def test_fused_random_policy_equals_separate_launches(name, B):
+    """ec_step_random_policy == ec_step followed by ec_random_policy(counter + steps taken) on the new mask: identical
+    actions, rewards and observations over an episode and across a reset."""
+    th = _th()
+    g = load_golden(name)
+    args = args_from_golden(g)
+    N = args.edge_node_num
+    envs = [_make_env(args, B, 3) for _ in range(2)]
+    acts = [th.empty(B, N, dtype=th.int64, device=e.device) for e in envs]
+    steps = 0
+    for t in range(130):
+        if t % args.episode_limit == 0:
+            for e, a in zip(envs, acts):
+                e.reset()
+                e.observe()
+                e.random_actions(seed=7, counter=1000 + t, out=a)
+        assert th.equal(acts[0], acts[1]), (t, "actions")
+        r0, _, i0 = envs[0].step(acts[0])                                         # separate launches
+        steps += 1
+        envs[0].random_actions(seed=7, counter=5 + steps, out=acts[0])
+        r1, _, i1, _ = envs[1].step_random_policy(acts[1], seed=7, counter=5)      # fused, in place
+        assert th.equal(r0, r1) and th.equal(i0["counters"], i1["counters"]), (t, "step outputs")
+        assert th.equal(envs[0].obs, envs[1].obs) and th.equal(envs[0].avail, envs[1].avail), (t, "observation")
+        assert bool((envs[1].avail.gather(-1, acts[1].unsqueeze(-1)) == 1).all()), (t, "drawn action not available")
+    for e in envs:
+        assert e.status() & ~32 == 0
+        e.close()
