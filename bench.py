@@ -111,31 +111,41 @@ def recorded_traffic():
 
 
 def measure_roofline(env, roll, n_steps):
-    """Average ec_step kernel duration from HIP events recorded on the launch stream around each launch,
-    plus the measured L-bar (live tasks/env) and D-bar (MT19937 doubles/env-step) of the same steps."""
+    """Average ec_step kernel duration from HIP events recorded on the launch stream around each launch (one pass with
+    no host synchronisation inside), then the measured L-bar (live tasks/env) and D-bar (MT19937 doubles/env-step) of
+    a second pass over the same number of steps."""
     import torch as th
+
+    def run(sample_live, events):
+        env.reset()
+        env.observe()
+        live = []
+        for t in range(n_steps):
+            if t and t % env.episode_limit == 0:
+                env.reset()
+                env.observe()
+            if t % env.episode_limit == 0:
+                env.random_actions(seed=0, counter=0, out=roll.actions, counter_dev=roll.counter_dev)
+            if events is not None:
+                a, b = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+                a.record()
+                env.step_random_policy(roll.actions, seed=0)
+                b.record()
+                events.append((a, b))
+            else:
+                env.step_random_policy(roll.actions, seed=0)
+            if sample_live and t % 10 == 5:
+                live.append(env.live_tasks() / env.n_envs)
+        th.cuda.synchronize(env.device)
+        return live
+
     th.cuda.synchronize(env.device)
-    cur0 = env.debug_rng_cursors().astype("float64").sum()
-    live = []
     pairs = []
-    env.reset()
-    env.observe()
-    for t in range(n_steps):
-        if t and t % env.episode_limit == 0:
-            env.reset()
-            env.observe()
-        if t % env.episode_limit == 0:
-            env.random_actions(seed=0, counter=0, out=roll.actions, counter_dev=roll.counter_dev)
-        a, b = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
-        a.record()
-        env.step_random_policy(roll.actions, seed=0)
-        b.record()
-        pairs.append((a, b))
-        if t % 10 == 5:
-            live.append(env.live_tasks() / env.n_envs)
-    th.cuda.synchronize(env.device)
+    run(False, pairs)
     ms = sorted(a.elapsed_time(b) for a, b in pairs)
     avg_ms = sum(ms) / len(ms)
+    cur0 = env.debug_rng_cursors().astype("float64").sum()
+    live = run(True, None)
     cur1 = env.debug_rng_cursors().astype("float64").sum()
     draws = (cur1 - cur0) / 2.0 / (n_steps * env.n_envs)
     lbar = sum(live) / max(1, len(live))
