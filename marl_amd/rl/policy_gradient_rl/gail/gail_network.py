@@ -4,6 +4,8 @@ import torch as th
 import torch.nn as nn
 import torch.nn.functional as F
 
+from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import SplitKLinear
+
 _ACT = {"relu": F.relu, "tanh": th.tanh, "leaky_relu": F.leaky_relu}
 
 
@@ -49,7 +51,7 @@ class Discriminator(nn.Module):
         h = args.hidden_dim
         widths = (args.obs_shape + args.n_agents + args.n_actions, h * 2, h, h // 2)
         for i, p in enumerate((0.3, 0.3, 0.2), start=1):
-            setattr(self, "fc%d" % i, nn.Linear(widths[i - 1], widths[i]))
+            setattr(self, "fc%d" % i, SplitKLinear(widths[i - 1], widths[i]))   # tall-batch weight gradients
             setattr(self, "bn%d" % i, nn.BatchNorm1d(widths[i]))
             setattr(self, "dropout%d" % i, nn.Dropout(p))
         self.fc4 = nn.Linear(widths[3], 1)

@@ -310,3 +310,41 @@ def test_network_mirrors_match_reference_fixtures(N):
         L = dd.compute_loss(sa, th.full((rows,), cval, dtype=th.long), th.from_numpy(g[tag + "dd_t_" + cname]).long(),
                             th.from_numpy(g[tag + "dd_noise_" + cname])).detach()
         assert th.allclose(L, th.from_numpy(g[tag + "dd_loss_" + cname]), rtol=1e-5, atol=1e-6)
+
+
+def test_splitk_linear_and_select_embedding_match_stock_autograd():
+    """SplitKLinear / _embed2 (dgail_network.py mirrors) give the stock modules' values and gradients, including the
+    double backward of DiffusionDiscriminator.compute_loss (create_graph=True)."""
+    import copy
+    from marl_amd.rl.policy_gradient_rl.dgail import dgail_network as dn
+    th.manual_seed(0)
+    rows = 9000                                            # above SplitKLinear.MIN_ROWS, not a multiple of the chunk
+    a = dn.SplitKLinear(20, 64).double()
+    b = th.nn.Linear(20, 64).double()
+    b.load_state_dict(a.state_dict())
+    x1 = th.randn(rows, 20, dtype=th.float64, requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    (a(x1).tanh().sum()).backward()
+    (b(x2).tanh().sum()).backward()
+    assert th.allclose(x1.grad, x2.grad, rtol=1e-12, atol=1e-14)
+    assert th.allclose(a.weight.grad, b.weight.grad, rtol=1e-10, atol=1e-12) and th.allclose(a.bias.grad, b.bias.grad, rtol=1e-10)
+
+    net = dn.DiffusionDiscriminator(20, 64).double()
+    ref = copy.deepcopy(net)
+    ref.forward = lambda x, t, c: ref.mlp(th.cat([x, ref.time_embed(t), ref.cond_embed(c)], dim=-1))   # stock embedding
+    for m in ref.mlp:
+        if isinstance(m, dn.SplitKLinear):
+            m.MIN_ROWS = 10 ** 9                                                                       # stock linear
+    sa = th.rand(rows, 20, dtype=th.float64)
+    t = th.randint(0, 2, (rows,))
+    noise = th.randn(rows, 20, dtype=th.float64)
+    c = th.randint(0, 2, (rows,))
+    for n in (net, ref):
+        n.train()
+    la = net.compute_loss(sa, c, t, noise)
+    lb = ref.compute_loss(sa, c, t, noise)
+    assert th.allclose(la, lb, rtol=1e-10, atol=1e-12)
+    la.mean().backward()
+    lb.mean().backward()
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert th.allclose(p.grad, q.grad, rtol=1e-8, atol=1e-11), k
