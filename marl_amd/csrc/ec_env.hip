@@ -1135,11 +1135,13 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
                     const bool succ = done && (exh[s] & KIND_SUCCESS);
                     const bool drop = done && !succ;
                     const u32 hop = exh[s] & 0xffffu;
+#ifndef ABL_NO_REW
                     rew = fail ? dadd(rew, d.pen_fail) : rew;
                     rew = drop ? dadd(rew, d.pen_drop) : rew;
                     rew = succ ? dadd(rew, d.rew_succ) : rew;
                     rew = succ ? dadd(rew, hop > 1 ? dmul(d.pen_hop, (double)(hop - 1)) : 0.0) : rew;
                     ct = done ? dadd(ct, exT[s]) : ct;
+#endif
                     n_fail += fail;
                     n_drop += drop;
                     n_succ += succ;
