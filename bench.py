@@ -38,7 +38,7 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
     p.add_argument("--roofline-steps", type=int, default=200)
-    p.add_argument("--threads", type=int, default=0, help="override threads per block of the step kernel")
+    p.add_argument("--geometry", default="", help="override the step kernel's launch geometry: epw,mw[,producers]")
     p.add_argument("--ppo-iters", type=int, default=3,
                    help="also time this many PPO iterations (rollout + update) at N=1 and report them beside the metric")
     return p.parse_args()
@@ -229,8 +229,11 @@ def main():
     dev = th.device("cuda:%d" % local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    if a.threads:
-        os.environ["MARL_AMD_EC_THREADS"] = str(a.threads)
+    if a.geometry:  # "envs per wave, main waves[, 0 = no RNG producer waves]" (default: chosen by ec_create)
+        g = [int(x) for x in a.geometry.split(",")]
+        os.environ["MARL_AMD_EC_EPW"], os.environ["MARL_AMD_EC_MW"] = str(g[0]), str(g[1])
+        if len(g) > 2:
+            os.environ["MARL_AMD_EC_PRODUCERS"] = str(g[2])
 
     ns = make_args(["--task_size_max=6000", "--seed=100", "--edge_node_num=%d" % a.nodes])
     B, N = a.envs, a.nodes

@@ -47,6 +47,7 @@ constexpr int RB_FAIL = 48;  // draws of the failure stream held in the LDS wind
 constexpr int AHEAD_FAIL = 2 * RB_FAIL;  // words regenerated ahead of the failure cursor at kernel entry
 constexpr int RB_TASK = 4;   // doubles of the task stream staged per refill (binomial + id + size + cycles)
 constexpr int AHEAD_TASK = 2 * RB_TASK;
+constexpr int AHEAD_MAX = 512;  // cap of the words kept regenerated ahead (a 64-word batch must not lap the cursor)
 constexpr int ACC_LDS = 256; // low part of the tick LUT kept in LDS
 
 // task record while in buffer_queue / new_task / a receiving queue (32 B)
@@ -100,6 +101,8 @@ struct EcDev {
     int N, A, k, D, S, T, H;
     int capB, capR, capW, maxTicks;
     int epb;       // environments per block (launch geometry)
+    int epw;       // environments per main wave of k_step (0: an env spans waves, lanes are contiguous)
+    int nmain;     // main threads per k_step block; threads beyond them are the RNG producer lanes
     int dl_ticks;  // (int)(deadline / mini_time_slot): starting point of the deadline searches
     FastDiv divN, divA;
     int64_t B, P;
@@ -380,6 +383,17 @@ struct RngFail {
         if (ahead >= 2 * n) stage_fresh(n);
         else stage(n);
     }
+    // consumer side of a window another lane has staged
+    __device__ __forceinline__ void attach(u32* mt_, u32 pos_, u32 ahead_, u32* buf_, int stride_, u32 n) {
+        mt = mt_;
+        pos = pos_;
+        ahead = ahead_;
+        buf = buf_;
+        stride = stride_;
+        used = 0;
+        staged = n;
+        idx = 0;
+    }
     // slide the window so that it starts at the next unconsumed draw (only when a lane's per-step bound exceeds
     // the window capacity)
     __device__ __forceinline__ void restage(u32 n) {
@@ -437,6 +451,17 @@ struct RngTask {
         used = 0;
         if (ahead >= 2u * RB_TASK) stage_fresh();
         else stage();
+    }
+    __device__ __forceinline__ void attach(u32* mt_, u32 pos_, u32 ahead_, double a, double b, double c, double e) {
+        mt = mt_;
+        pos = pos_;
+        ahead = ahead_;
+        used = 0;
+        idx = 0;
+        u0 = a;
+        u1 = b;
+        u2 = c;
+        u3 = e;
     }
     __device__ __forceinline__ double next() {
         if (idx == (u32)RB_TASK) {  // only after a binomial redraw
@@ -553,14 +578,37 @@ __device__ __forceinline__ void generate_task(const EcDev& d, int64_t lane, doub
 struct LaneId {
     int64_t env, lane;
     int node, env_local;
+    int lidx;  // env_local * N + node: index of the lane in the block's per-lane LDS arrays
     bool valid;
 };
-__device__ __forceinline__ LaneId lane_id(const EcDev& d) {
+// lanes packed contiguously over the block's threads, starting at thread t0
+__device__ __forceinline__ LaneId lane_id(const EcDev& d, int t0 = 0) {
     LaneId L;
-    L.env_local = (int)fdiv(threadIdx.x, d.divN);
-    L.node = threadIdx.x - L.env_local * d.N;
+    const u32 t = threadIdx.x - t0;
+    L.env_local = (int)fdiv(t, d.divN);
+    L.node = t - L.env_local * d.N;
+    L.lidx = (int)t;
     L.env = (int64_t)blockIdx.x * d.epb + L.env_local;
-    L.valid = L.env_local < d.epb && L.env < d.B;
+    L.valid = (int)threadIdx.x >= t0 && L.env_local < d.epb && L.env < d.B;
+    L.lane = L.env * d.N + L.node;
+    return L;
+}
+// main lanes of k_step: whole envs per wave (d.epw of them) so that a block of several waves keeps the
+// per-wave divergence of a one-wave block; contiguous when one env needs more than a wave
+__device__ __forceinline__ LaneId lane_id_main(const EcDev& d) {
+    if (d.epw == 0) {
+        LaneId L = lane_id(d);
+        L.valid = L.valid && (int)threadIdx.x < d.nmain;
+        return L;
+    }
+    LaneId L;
+    const u32 w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const int el = (int)fdiv(l, d.divN);
+    L.node = l - el * d.N;
+    L.env_local = (int)w * d.epw + el;
+    L.lidx = L.env_local * d.N + L.node;
+    L.env = (int64_t)blockIdx.x * d.epb + L.env_local;
+    L.valid = (int)threadIdx.x < d.nmain && el < d.epw && L.env_local < d.epb && L.env < d.B;
     L.lane = L.env * d.N + L.node;
     return L;
 }
@@ -665,13 +713,14 @@ __device__ __forceinline__ void observe_block(const EcDev& d, const LaneId& L, u
                                               const Rec& newt, float* __restrict__ obs, int32_t* __restrict__ avail,
                                               u32* s_full, u32* s_hasnew, u32* s_any, float* s_obs) {
     const int N = d.N, A = d.A;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x;  // cooperative copy loops
+    const int li = L.lidx;        // this lane's slot in the per-lane arrays
     const int epb = d.epb;
     if (L.valid) {
-        s_full[tid] = ((double)wq_len >= d.qthr[L.node]) ? 1u : 0u;  // edge_node.py:186-188
-        s_hasnew[tid] = has_new;
+        s_full[li] = ((double)wq_len >= d.qthr[L.node]) ? 1u : 0u;  // edge_node.py:186-188
+        s_hasnew[li] = has_new;
         if (obs) {
-            float* o = s_obs + tid * 9;
+            float* o = s_obs + li * 9;
             o[0] = d.obs_const[L.node * 3 + 0];
             o[1] = d.obs_const[L.node * 3 + 1];
             o[2] = d.obs_const[L.node * 3 + 2];
@@ -702,7 +751,7 @@ __device__ __forceinline__ void observe_block(const EcDev& d, const LaneId& L, u
             } else {
                 for (int j = 0; j < N; j++) any |= (d.adj[L.node * A + j] && !full[j]) ? 1u : 0u;
             }
-            s_any[tid] = any;
+            s_any[li] = any;
         }
         __syncthreads();
         const int total = (int)nenv * N * A;
@@ -766,7 +815,10 @@ struct StepLds {
     double* rew;     // [NT]
     double* ct;      // [NT]
     u32* cnt;        // [4][NT]
+    double* tu;      // [RB_TASK][NT] the step's task-stream doubles (producer -> consumer)
+    u32* rc;         // [RC_N][NT] RNG cursors and the producer/consumer hand-off (RC_*)
 };
+enum { RC_FPOS, RC_FAHEAD, RC_TPOS, RC_TAHEAD, RC_FDELTA, RC_TDELTA, RC_DONE, RC_NX, RC_N };
 __host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int capW) {
     size_t b = 0;
     b += sizeof(double) * ACC_LDS;
@@ -775,6 +827,7 @@ __host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int
     b += (size_t)NT * DMAX * (32 + 5 * 4);
     b += (size_t)NT * (RB_FAIL + 1) * 4;
     b += (size_t)NT * (8 + 8 + 16);
+    b += (size_t)NT * (RB_TASK * 8 + RC_N * 4);
     return b + 64;
 }
 
@@ -810,7 +863,7 @@ __device__ __forceinline__ u64 policy_hash(u64 seed, u64 counter, u64 rows, u64 
 // KMAX >= k and DMAX >= max in-degree are compile-time so that the executing slots and the receiving-queue
 // scalars live in registers and the per-mini-slot work is branch-free except for events.
 template <int KMAX, int DMAX>
-__global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict__ actions, float* __restrict__ reward,
+__global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(EcDev d, const int64_t* __restrict__ actions, float* __restrict__ reward,
                                               uint8_t* __restrict__ terminated, int32_t* __restrict__ counters,
                                               float* __restrict__ completion_time, float* __restrict__ next_obs,
                                               int32_t* __restrict__ next_avail, StepPolicy pol) {
@@ -818,7 +871,6 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
     static_assert(RB_FAIL * 4 >= 12 + 36, "observation scratch does not fit the failure window");
     extern __shared__ __align__(16) unsigned char smem[];
     const int NT = d.epb * d.N;  // active lanes of the block = stride of the per-lane LDS arrays
-    const int tid = threadIdx.x;
     const int N = d.N, D = d.D;
     const int64_t P = d.P;
     const u32 wmask = (u32)d.capW - 1;  // capW is a power of two
@@ -833,6 +885,7 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         S.exC = reinterpret_cast<u64*>(p);       p += (size_t)NT * KMAX * 8;
         S.rew = reinterpret_cast<double*>(p);    p += (size_t)NT * 8;
         S.ct = reinterpret_cast<double*>(p);     p += (size_t)NT * 8;
+        S.tu = reinterpret_cast<double*>(p);     p += (size_t)NT * RB_TASK * 8;
         S.fa = reinterpret_cast<u32*>(p);        p += (size_t)NT * (RB_FAIL + 1) * 4;
         S.rqhs = reinterpret_cast<u32*>(p);      p += (size_t)NT * DMAX * 4;
         S.rqhead = reinterpret_cast<u32*>(p);    p += (size_t)NT * DMAX * 4;
@@ -840,15 +893,24 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         S.rqlen = reinterpret_cast<u32*>(p);     p += (size_t)NT * DMAX * 4;
         S.rqarr = reinterpret_cast<u32*>(p);     p += (size_t)NT * DMAX * 4;
         S.cnt = reinterpret_cast<u32*>(p);       p += (size_t)NT * 16;
+        S.rc = reinterpret_cast<u32*>(p);        p += (size_t)NT * RC_N * 4;
     }
     Lut lut{d, (lds_cdouble_ptr)S.acc, 0u};
 
     {  // block-shared low part of the tick LUT
         const int nacc = d.maxTicks + 1 < ACC_LDS ? d.maxTicks + 1 : ACC_LDS;
-        for (int i = tid; i < nacc; i += blockDim.x) S.acc[i] = d.acc[i];
+        for (int i = threadIdx.x; i < nacc; i += blockDim.x) S.acc[i] = d.acc[i];
     }
 
-    const LaneId L = lane_id(d);
+    // Two roles.  The main lanes (threads < d.nmain) run the env logic and only CONSUME random words.  The RNG
+    // producer lanes regenerate the Mersenne-Twister states and stage the step's draws: a wave of their own
+    // when the block was launched with more than d.nmain threads (its memory latency then overlaps the main
+    // waves' dependent chain), else the main lanes themselves at the same program points.
+    const bool has_producers = (int)blockDim.x > d.nmain;
+    const LaneId L = lane_id_main(d);
+    const LaneId R = has_producers ? lane_id(d, d.nmain) : L;
+    const bool producer_wave = has_producers ? (int)threadIdx.x >= d.nmain : true;  // wave-uniform
+    const int tid = L.lidx;  // slot of this main lane in the per-lane LDS arrays
     const int64_t lane = L.lane;
     const int node = L.node;
     EC_STAMP(0);
@@ -858,10 +920,9 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
     bool wq_dirty = false;
     int deg = 0;
     int64_t action = N;
-    u32 exA_thr = 0, exB_thr = 0;          // execution failure threshold M = A << 26 | B
-    u32 lkA[DMAX], lkB[DMAX];              // per in-link transmission failure thresholds
-    double cap = 1.0, rate = 0.0, bin_qn = 0.0, bin_px2 = 0.0;
-    u32 bin_flip = 0;
+    u32 exA_thr = 0;                       // execution failure threshold M = A << 26 | B: A (B is re-read on a tie)
+    u32 lkA[DMAX];                         // per in-link transmission failure thresholds, likewise
+    double cap = 1.0, rate = 0.0;
     int slot = -1;
     Rec newt;
     newt.size = newt.cycles = 0;
@@ -872,7 +933,6 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
     buf.head = buf.len = 0;
     buf.head_rec = newt;
     RngFail frng;
-    RngTask trng;
     // executing slots: exw = cet | fin << 16 (fin: the cet at which the task drops or completes),
     // exh = hop | KIND_SUCCESS, exT = the reference's task_time at cet == fin
     u32 exw[KMAX], exh[KMAX];
@@ -888,7 +948,6 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         rql[s] = 0;
         rqa[s] = NEVER;
         lkA[s] = 0xffffffffu;
-        lkB[s] = 0;
     }
     u32 steps_before = 0;
     if (L.valid) {
@@ -904,12 +963,7 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         deg = d.deg[node];
         const u64 me = d.thr_exec_m[node];
         exA_thr = (u32)(me >> 26);
-        exB_thr = (u32)(me & 0x3ffffffull);
         cap = d.cap[node];
-        bin_qn = d.bin_qn[node];
-        bin_px2 = d.bin_px2[node];
-        bin_flip = d.bin_flip[node];
-        const u32 tpos = d.rng_pos[lane], tahead = d.rng_ahead[lane];
         if (has_new) newt = load_rec(d.newt + lane);
         if (buf.len > 0) buf.head_rec = load_rec(d.buf + (size_t)buf.head * P + lane);
         if (has_new && action >= 0 && action < N && action != node) {
@@ -945,7 +999,6 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
                 S.rqdirty[s * NT + tid] = 0;
                 const u64 ml = d.thr_link_m[node * D + s];
                 lkA[s] = (u32)(ml >> 26);
-                lkB[s] = (u32)(ml & 0x3ffffffull);
                 if (ql > 0) {
                     const uint4* q = reinterpret_cast<const uint4*>(d.rq + ((size_t)s * d.capR + qh) * P + lane);
                     S.rqrec[(s * 2 + 0) * NT + tid] = q[0];
@@ -953,12 +1006,26 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
                 }
             }
         }
-#ifdef ABL_NO_TRNG
-        trng.mt = d.mt + (size_t)lane * MT_STRIDE; trng.pos = tpos; trng.ahead = 8; trng.idx = 0; trng.used = 0;
-        trng.u0 = 0.3; trng.u1 = 0.4; trng.u2 = 0.5; trng.u3 = 0.6;
-#else
-        trng.open(d.mt + (size_t)lane * MT_STRIDE, tpos, tahead);
-#endif
+    }
+    // producer, part 1: this step's task doubles and the failure window, straight from the words regenerated
+    // ahead of the cursors during the previous step (per-lane regeneration only if that invariant is absent)
+    if (R.valid) {
+        const int ri = R.lidx;
+        const size_t tl = (size_t)R.lane, fl = (size_t)P + (size_t)R.lane;
+        const u32 tpos = d.rng_pos[tl], tah = d.rng_ahead[tl], fpos = d.rng_pos[fl], fah = d.rng_ahead[fl];
+        RngTask pt;
+        pt.open(d.mt + tl * MT_STRIDE, tpos, tah);
+        S.tu[0 * NT + ri] = pt.u0;
+        S.tu[1 * NT + ri] = pt.u1;
+        S.tu[2 * NT + ri] = pt.u2;
+        S.tu[3 * NT + ri] = pt.u3;
+        RngFail pf;
+        pf.open(d.mt + fl * MT_STRIDE, fpos, fah, S.fa + ri, NT, (u32)RB_FAIL);
+        S.rc[RC_FPOS * NT + ri] = fpos;
+        S.rc[RC_FAHEAD * NT + ri] = pf.ahead;
+        S.rc[RC_TPOS * NT + ri] = tpos;
+        S.rc[RC_TAHEAD * NT + ri] = pt.ahead;
+        S.rc[RC_DONE * NT + ri] = 0;
     }
     __syncthreads();
     EC_STAMP(1);
@@ -1026,8 +1093,38 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
             }
         }
     }
+    if (L.valid) S.rc[RC_NX * NT + tid] = ex_n + wq_len;
     __syncthreads();  // pushes into the LDS queue heads are visible to their destination lanes
     EC_STAMP(2);
+
+    // producer, part 2 (concurrent with the mini-slots when it has a wave of its own): regenerate both streams
+    // far enough ahead that the NEXT step finds its window and task doubles ready whatever this step consumes
+    if (producer_wave) {
+        u32 tpos = 0, tah = 0, fpos = 0, fah = 0, want_f = 0;
+        const int ri = R.lidx;
+        if (R.valid) {
+            fpos = S.rc[RC_FPOS * NT + ri];
+            fah = S.rc[RC_FAHEAD * NT + ri];
+            tpos = S.rc[RC_TPOS * NT + ri];
+            tah = S.rc[RC_TAHEAD * NT + ri];
+            u32 n_ne = 0;
+            const int rdeg = d.deg[R.node];
+            for (int s = 0; s < rdeg; s++) n_ne += S.rqlen[s * NT + ri] > 0 ? 1u : 0u;
+            const u32 nx = S.rc[RC_NX * NT + ri];
+            const u32 bound = (u32)d.S * ((nx < (u32)d.k ? nx : (u32)d.k) + n_ne);  // the step's draw bound, as below
+            want_f = (u32)AHEAD_FAIL + 2u * bound;
+            want_f = want_f < (u32)AHEAD_MAX ? want_f : (u32)AHEAD_MAX;
+        }
+        const u32 fah0 = fah, tah0 = tah;
+        mt_coop_refill(d.mt, (u64)(R.valid ? R.lane : 0), tpos, tah, 2u * AHEAD_TASK, R.valid);
+        mt_coop_refill(d.mt, (u64)P + (u64)(R.valid ? R.lane : 0), fpos, fah, want_f, R.valid);
+        if (R.valid) {
+            S.rc[RC_FDELTA * NT + ri] = fah - fah0;
+            S.rc[RC_TDELTA * NT + ri] = tah - tah0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the regenerated words before the flag
+            __hip_atomic_store(&S.rc[RC_DONE * NT + ri], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
 
     // ---------------------------------------------------------------- failure-stream window
     // Within a step no queue gains a task after phase A, so this bounds the lane's draws: per mini-slot at most
@@ -1045,15 +1142,10 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         }
         const u32 n_ex = ex_n + wq_len < (u32)d.k ? ex_n + wq_len : (u32)d.k;
         draw_bound = (u32)d.S * (n_ex + n_ne);
-#ifdef ABL_NO_FRNG
-        frng.open(d.mt + ((size_t)P + lane) * MT_STRIDE, d.rng_pos[P + lane], d.rng_ahead[P + lane], S.fa + tid, NT, 0);
-        frng.staged = RB_FAIL;
-        draw_bound = 0;
-#else
-        frng.open(d.mt + ((size_t)P + lane) * MT_STRIDE, d.rng_pos[P + lane], d.rng_ahead[P + lane], S.fa + tid, NT,
-                  draw_bound < (u32)RB_FAIL ? draw_bound : (u32)RB_FAIL);
-#endif
+        frng.attach(d.mt + ((size_t)P + lane) * MT_STRIDE, S.rc[RC_FPOS * NT + tid], S.rc[RC_FAHEAD * NT + tid],
+                    S.fa + tid, NT, (u32)RB_FAIL);
     }
+    bool f_synced = false;  // frng.ahead includes the producer's part-2 regeneration
 
     EC_STAMP(3);
     // ---------------------------------------------------------------- phase B: mini-slots, edge_computing_env.py:101-105
@@ -1099,6 +1191,14 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
 #pragma unroll
             for (int s = 0; s < DMAX; s++) n_ne += rql[s] > 0 ? 1u : 0u;
             if (frng.idx + ex_n + n_ne > frng.staged) {
+                if (!f_synced) {
+                    // the producer may still be regenerating this stream: wait for it (it never waits for us)
+                    while (__hip_atomic_load(&S.rc[RC_DONE * NT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+                        __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    frng.ahead += S.rc[RC_FDELTA * NT + tid];
+                    f_synced = true;
+                }
                 const u32 left = draw_bound - (frng.used + frng.idx);  // the bound only shrinks as draws are spent
                 frng.restage(left < (u32)RB_FAIL ? left : (u32)RB_FAIL);
             }
@@ -1130,7 +1230,8 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
                     const u32 cet = (exw[s] & 0xffffu) + 1;
                     const u32 fin = exw[s] >> 16;
                     bool fail = act && ae[s] > exA_thr;
-                    if (act && ae[s] == exA_thr) fail = frng.b_of(base + s) > exB_thr;  // 2^-27 tie on the first word
+                    if (act && ae[s] == exA_thr)  // 2^-27 tie on the first word
+                        fail = frng.b_of(base + s) > (u32)(d.thr_exec_m[node] & 0x3ffffffull);
                     const bool done = act && !fail && cet >= fin;
                     const bool succ = done && (exh[s] & KIND_SUCCESS);
                     const bool drop = done && !succ;
@@ -1223,7 +1324,8 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
             for (int s = 0; s < DMAX; s++) {
                 const bool ne = rql[s] > 0;
                 bool failed = ne && ar[s] > lkA[s];
-                if (ne && ar[s] == lkA[s]) failed = frng.b_of(ir[s]) > lkB[s];  // 2^-27 tie on the first word
+                if (ne && ar[s] == lkA[s])  // 2^-27 tie on the first word
+                    failed = frng.b_of(ir[s]) > (u32)(d.thr_link_m[node * D + s] & 0x3ffffffull);
                 const bool arrived = ne && !failed && c >= rqa[s];
                 rew = failed ? dadd(rew, d.pen_fail) : rew;
                 n_fail += failed;
@@ -1307,10 +1409,21 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
     EC_STAMP(5);
     // ---------------------------------------------------------------- phase D: generate_task (:127-128) + write-back
     double wait_sum = 0.0;
+    Rec nnew;  // generate_task always clears new_task first (edge_node.py:160): the old record is dead by now
+    nnew.size = nnew.cycles = 0;
+    nnew.twt = nnew.ctt = nnew.hop = nnew.ntx = 0;
+    nnew.bwt = 0;
+    nnew.enq = 0;
     if (L.valid) {
-        generate_task(d, lane, bin_qn, bin_px2, bin_flip, trng, buf, n_off, has_new, newt);
+        // past the barrier above the producer has finished: its regeneration counts, and the streams are ours
+        if (!f_synced) frng.ahead += S.rc[RC_FDELTA * NT + tid];
+        RngTask trng;
+        trng.attach(d.mt + (size_t)lane * MT_STRIDE, S.rc[RC_TPOS * NT + tid],
+                    S.rc[RC_TAHEAD * NT + tid] + S.rc[RC_TDELTA * NT + tid], S.tu[0 * NT + tid], S.tu[1 * NT + tid],
+                    S.tu[2 * NT + tid], S.tu[3 * NT + tid]);
+        generate_task(d, lane, d.bin_qn[node], d.bin_px2[node], d.bin_flip[node], trng, buf, n_off, has_new, nnew);
         d.has_new[lane] = has_new;
-        if (has_new) store_rec(d.newt + lane, newt);
+        if (has_new) store_rec(d.newt + lane, nnew);
         d.n_off[lane] = n_off;
         d.buf_head[lane] = buf.head;
         d.buf_len[lane] = buf.len;
@@ -1361,21 +1474,6 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         if (ovf | lut.ovf) flag(d, EC_ST_TICK_OVERFLOW);
     }
     EC_STAMP(6);
-    {   // regenerate ahead for the next step (whole wave per stream, coalesced)
-        u32 tpos = 0, tah = 0, fpos = 0, fah = 0, dr;
-        if (L.valid) {
-            trng.close(tpos, tah, dr);
-            frng.close(fpos, fah, dr);
-        }
-        const u32 tah0 = tah, fah0 = fah;
-        mt_coop_refill(d.mt, (u64)(L.valid ? lane : 0), tpos, tah, AHEAD_TASK, L.valid);
-        mt_coop_refill(d.mt, (u64)P + (u64)(L.valid ? lane : 0), fpos, fah, AHEAD_FAIL, L.valid);
-        if (L.valid) {
-            if (tah != tah0) d.rng_ahead[lane] = tah;
-            if (fah != fah0) d.rng_ahead[P + lane] = fah;
-        }
-    }
-
     EC_STAMP(7);
     // ---------------------------------------------------------------- phase E: fused observation of the new state
 #ifdef ABL_NO_OBS
@@ -1388,7 +1486,7 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         u32* s_hasnew = s_full + NT;
         u32* s_any = s_hasnew + NT;
         float* s_obs = reinterpret_cast<float*>(s_any + NT);
-        observe_block(d, L, wq_len, wait_sum, has_new, newt, next_obs, next_avail, s_full, s_hasnew, s_any, s_obs);
+        observe_block(d, L, wq_len, wait_sum, has_new, nnew, next_obs, next_avail, s_full, s_hasnew, s_any, s_obs);
         if (pol.next_actions) {
             // s_full / s_hasnew / s_any still hold the mask's ingredients (edge_node.py:179-197)
             // every env of the handle has taken the same number of steps: a launch counter without atomics
@@ -1637,6 +1735,7 @@ struct ec_env {
     int device;
     int threads;       // per block
     int envs_per_block;
+    int threads_obs;  // block size of k_observe (the block's lanes, contiguous)
     int64_t blocks;
     size_t lds_step, lds_obs;
     step_fn step;
@@ -1847,47 +1946,87 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     EC_TRY(dev_alloc(h, &d.status, 1, true));
     d.stamps = nullptr;
 
-    // launch geometry: whole envs per block (one wave for N <= 64).  The step is bound by the dependent chain
-    // of one wave, not by bandwidth, so a launch whose blocks are not all co-resident costs a second full round:
-    // pick the fewest environments per block (less divergence per wave) that still fits the chip in one round,
-    // and the densest packing once the batch is too large for that.
-    int threads = ((N + 63) / 64) * 64;
-    if (const char* e = getenv("MARL_AMD_EC_THREADS")) threads = atoi(e);
-    if (threads < N || threads > 256 || threads % 64 != 0)
-        return ec::fail(EC_EINVAL, "threads per block %d unsupported (n_nodes=%d)", threads, N);
+    // Launch geometry of k_step.  The step is bound by the dependent chain of one wave, not by bandwidth, so
+    //  * a launch whose blocks are not all co-resident costs a second full round: every block must be resident;
+    //  * fewer environments per main wave mean less divergence per wave;
+    //  * the RNG producer lanes get a wave of their own (one per 64 lanes of the block) when that still fits.
+    // Candidates in order of preference: producers yes/no is tried per (envs per wave, main waves) pair, envs
+    // per wave ascending, main waves ascending (more of them share one producer wave and one LUT copy).
     h->step = pick_step(d.k, D, &h->kmax, &h->dmax);
     if (!h->step) return ec::fail(EC_EINVAL, "k=%d / max in-degree %d exceed the compiled limits (12 / 8)", d.k, D);
-    const int epb_max = threads / N;
-    int epb = epb_max;
-    if (const char* e = getenv("MARL_AMD_EC_EPB")) {
-        epb = atoi(e);
+    const void* fn = reinterpret_cast<const void*>(h->step);
+    hipDeviceProp_t prop;
+    EC_HIP(hipGetDeviceProperties(&prop, h->device));
+    struct Geo {
+        int epw, mw, pw;  // envs per main wave (0: one env over mw waves), main waves, producer waves
+        int epb() const { return epw == 0 ? 1 : epw * mw; }
+        int threads() const { return 64 * (mw + pw); }
+    };
+    auto geo_fits = [&](const Geo& g, size_t* lds_out, bool* resident) -> int {
+        const size_t lds = step_lds_bytes(g.epb() * N, h->kmax, h->dmax, d.capW);
+        *lds_out = lds;
+        *resident = false;
+        if (lds > 160 * 1024 || g.threads() > 256) return EC_OK;
+        EC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0;
+        EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, g.threads(), lds));
+        *resident = (B + g.epb() - 1) / g.epb() <= (int64_t)per_cu * prop.multiProcessorCount;
+        return EC_OK;
+    };
+    const bool want_producers = !(getenv("MARL_AMD_EC_PRODUCERS") && atoi(getenv("MARL_AMD_EC_PRODUCERS")) == 0);
+    Geo geo{0, 0, 0};
+    bool found = false;
+    if (N > 64) {
+        const int mw = (N + 63) / 64;
+        if (mw > 4) return ec::fail(EC_EINVAL, "n_nodes=%d exceeds 256 lanes per env", N);
+        geo = Geo{0, mw, (want_producers && 2 * mw <= 4) ? mw : 0};
+        found = true;
+    } else if (getenv("MARL_AMD_EC_EPW") && getenv("MARL_AMD_EC_MW")) {
+        geo.epw = atoi(getenv("MARL_AMD_EC_EPW"));
+        geo.mw = atoi(getenv("MARL_AMD_EC_MW"));
+        if (geo.epw < 1 || geo.epw * N > 64 || geo.mw < 1 || geo.mw > 4)
+            return ec::fail(EC_EINVAL, "envs per wave %d x main waves %d unsupported (n_nodes=%d)", geo.epw, geo.mw, N);
+        geo.pw = want_producers ? (geo.epw * geo.mw * N + 63) / 64 : 0;
+        if (geo.threads() > 256) return ec::fail(EC_EINVAL, "%d threads per block exceed 256", geo.threads());
+        found = true;
     } else {
-        hipDeviceProp_t prop;
-        EC_HIP(hipGetDeviceProperties(&prop, h->device));
-        for (int cand = 1; cand <= epb_max; cand++) {
-            const size_t lds = step_lds_bytes(cand * N, h->kmax, h->dmax, d.capW);
-            if (lds > 160 * 1024) break;
-            EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->step),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            int per_cu = 0;
-            EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(h->step), threads, lds));
-            const int64_t resident = (int64_t)per_cu * prop.multiProcessorCount;
-            if ((B + cand - 1) / cand <= resident) {
-                epb = cand;
-                break;
+        const int epw_max = 64 / N;
+        for (int pass = want_producers ? 0 : 1; pass < 2 && !found; pass++) {  // pass 0: with producer waves
+            for (int epw = 1; epw <= epw_max && !found; epw++) {
+                for (int mw = 1; mw <= 4 && !found; mw++) {
+                    Geo g{epw, mw, pass == 0 ? (epw * mw * N + 63) / 64 : 0};
+                    size_t lds;
+                    bool resident;
+                    EC_TRY(geo_fits(g, &lds, &resident));
+                    if (resident) {
+                        geo = g;
+                        found = true;
+                    }
+                }
+            }
+        }
+        if (!found) {  // too large for one round: densest packing, no producer waves
+            geo = Geo{epw_max, 1, 0};
+            for (int mw = 4; mw > 1; mw--) {
+                if (step_lds_bytes(epw_max * mw * N, h->kmax, h->dmax, d.capW) <= 64 * 1024) {
+                    geo.mw = mw;
+                    break;
+                }
             }
         }
     }
-    if (epb < 1 || epb * N > threads) return ec::fail(EC_EINVAL, "envs per block %d does not fit %d threads", epb, threads);
+    const int epb = geo.epb();
     d.epb = epb;
-    h->threads = threads;
+    d.epw = geo.epw;
+    d.nmain = 64 * geo.mw;
+    h->threads = geo.threads();
+    h->threads_obs = ((epb * N + 63) / 64) * 64;
     h->envs_per_block = epb;
     h->blocks = (B + epb - 1) / epb;
     h->lds_obs = (size_t)epb * N * (3 * 4 + 9 * 4);
     h->lds_step = step_lds_bytes(epb * N, h->kmax, h->dmax, d.capW);
     if (h->lds_step > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_step);
-    EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->step), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)h->lds_step));
+    EC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
 #ifdef EC_STAMPS
     EC_TRY(dev_alloc(h, &d.stamps, (size_t)h->blocks * 16, true));
 #endif
@@ -1953,7 +2092,7 @@ int ec_reset(ec_handle h, void* stream) {
 int ec_observe(ec_handle h, float* obs, int32_t* avail, void* stream) {
     if (!h) return ec::fail(EC_EINVAL, "null handle");
     if (!obs && !avail) return EC_OK;
-    hipLaunchKernelGGL(k_observe, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_obs, (hipStream_t)stream, h->d,
+    hipLaunchKernelGGL(k_observe, dim3((unsigned)h->blocks), dim3(h->threads_obs), h->lds_obs, (hipStream_t)stream, h->d,
                        obs, avail);
     EC_HIP(hipGetLastError());
     return EC_OK;
@@ -2065,10 +2204,11 @@ int ec_debug_live_tasks(ec_handle h, int64_t* total_host) {
 
 int ec_info(ec_handle h, int64_t* info_host, int32_t n) {
     if (!h || !info_host) return ec::fail(EC_EINVAL, "null argument");
-    const int64_t v[13] = {h->d.B, h->d.N, h->d.k, h->d.D, h->d.capB, h->d.capR, h->d.capW, h->d.maxTicks,
+    const int64_t v[16] = {h->d.B, h->d.N, h->d.k, h->d.D, h->d.capB, h->d.capR, h->d.capW, h->d.maxTicks,
                            h->threads, h->envs_per_block, (int64_t)(h->state_bytes & 0xffffffffull),
-                           (int64_t)(h->state_bytes >> 32), (int64_t)h->lds_step};
-    for (int i = 0; i < n && i < 13; i++) info_host[i] = v[i];
+                           (int64_t)(h->state_bytes >> 32), (int64_t)h->lds_step,
+                           h->d.epw, h->d.nmain / 64, (h->threads - h->d.nmain) / 64};
+    for (int i = 0; i < n && i < 16; i++) info_host[i] = v[i];
     return EC_OK;
 }
 
