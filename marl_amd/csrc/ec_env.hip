@@ -47,6 +47,7 @@ constexpr int RB_FAIL = 48;  // draws of the failure stream held in the LDS wind
 constexpr int AHEAD_FAIL = 2 * RB_FAIL;  // words regenerated ahead of the failure cursor at kernel entry
 constexpr int RB_TASK = 4;   // doubles of the task stream staged per refill (binomial + id + size + cycles)
 constexpr int AHEAD_TASK = 2 * RB_TASK;
+constexpr int RB_EARLY = 16;  // draws of the window staged before the step's first barrier; the rest follows during the mini-slots
 constexpr int AHEAD_MAX = 512;  // cap of the words kept regenerated ahead (a 64-word batch must not lap the cursor)
 constexpr int ACC_LDS = 256; // low part of the tick LUT kept in LDS
 
@@ -183,12 +184,35 @@ struct Lut {
         if (n < (u32)ACC_LDS) return s_acc[n];
         return d.acc[n];
     }
+    // acc[n .. n+3] (indices clamped to the LUT) with the four loads in flight together: the searches below
+    // advance four candidates per memory round trip instead of one
+    __device__ __forceinline__ void peek4(u32 n, double (&a)[4]) const {
+        const u32 mx = (u32)d.maxTicks;
+        u32 i[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) i[j] = n + j > mx ? mx : n + j;
+        if (i[3] < (u32)ACC_LDS) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[j] = s_acc[i[j]];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[j] = d.acc[i[j]];
+        }
+    }
     // smallest n with acc[n] >= x, T16_NEVER if none in the LUT
     __device__ __forceinline__ u32 ticks_to_reach(double x) const {
-        const double est = x * d.inv_dt;  // only a starting point: the search below is exact
+        // starting point only.  acc[n] is n * dt up to accumulated rounding, so the answer is floor(est) or
+        // floor(est) + 1 and any start at or below it gives the same result (acc is non-decreasing)
+        const double est = x * d.inv_dt;
         u32 n = 0;
-        if (est > 3.0) n = est >= (double)d.maxTicks ? (u32)d.maxTicks : (u32)est - 3u;
-        while (n <= (u32)d.maxTicks && at(n) < x) n++;
+        if (est > 2.0) n = est >= (double)d.maxTicks ? (u32)d.maxTicks : (u32)est - 2u;
+        while (n <= (u32)d.maxTicks) {
+            double a[4];
+            peek4(n, a);  // acc is non-decreasing: the first candidate to reach x is the count of those below it
+            const u32 below = (a[0] < x ? 1u : 0u) + (a[1] < x ? 1u : 0u) + (a[2] < x ? 1u : 0u) + (a[3] < x ? 1u : 0u);
+            n += below;
+            if (below < 4u) break;
+        }
         return n > (u32)d.maxTicks ? T16_NEVER : n;
     }
     // The reference's task_time (edge_node.py:255,301): ((((ewt + cet) + twt) + ctt) + bwt) in fp64.
@@ -203,13 +227,21 @@ struct Lut {
         u32 n = nominal < 1 ? 1u : (u32)nominal;
         const double tail0 = at(twt), tail1 = at(ctt), tail2 = at(bwt), fixed = which ? at(ewt) : 0.0;
         while (n <= (u32)d.maxTicks) {
-            const double head = which ? dadd(fixed, at(n)) : dadd(at(n), 0.0);
-            const double tt = dadd(dadd(dadd(head, tail0), tail1), tail2);
-            if (tt > d.deadline) {
-                *tt_out = tt;
-                return n;
+            double a[4], tt[4];
+            peek4(n, a);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const double head = which ? dadd(fixed, a[j]) : dadd(a[j], 0.0);
+                tt[j] = dadd(dadd(dadd(head, tail0), tail1), tail2);
             }
-            n++;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (n + j <= (u32)d.maxTicks && tt[j] > d.deadline) {
+                    *tt_out = tt[j];
+                    return n + j;
+                }
+            }
+            n += 4;
         }
         *tt_out = 0.0;
         return T16_NEVER;
@@ -708,16 +740,20 @@ __global__ void k_reset(EcDev d) {
 
 // Observation + availability mask for the envs of this block (edge_node.py:109-136,179-197).
 // Per lane in: wq_len, `wait_sum` = get_waiting_time() (fp64, queue order), has_new/newt.
-// LDS scratch: s_full/s_hasnew/s_any [NT] (NT = active lanes), s_obs [NT*9].
+// LDS scratch: s_full/s_hasnew/s_any [NT] (NT = active lanes), s_obs [NT*9], s_fullbits [epb] or null.
+// With s_fullbits (requires d.adj_bits and every env's lanes consecutive in ONE wave, node 0 first) the "queue
+// full" flags of an env travel as one ballot word and the second barrier + s_any pass are not needed.
 __device__ __forceinline__ void observe_block(const EcDev& d, const LaneId& L, u32 wq_len, double wait_sum, u32 has_new,
                                               const Rec& newt, float* __restrict__ obs, int32_t* __restrict__ avail,
-                                              u32* s_full, u32* s_hasnew, u32* s_any, float* s_obs) {
+                                              u32* s_full, u32* s_hasnew, u32* s_any, float* s_obs, u64* s_fullbits) {
     const int N = d.N, A = d.A;
     const int tid = threadIdx.x;  // cooperative copy loops
     const int li = L.lidx;        // this lane's slot in the per-lane arrays
     const int epb = d.epb;
+    bool full = false;
     if (L.valid) {
-        s_full[li] = ((double)wq_len >= d.qthr[L.node]) ? 1u : 0u;  // edge_node.py:186-188
+        full = (double)wq_len >= d.qthr[L.node];  // edge_node.py:186-188
+        s_full[li] = full ? 1u : 0u;
         s_hasnew[li] = has_new;
         if (obs) {
             float* o = s_obs + li * 9;
@@ -737,23 +773,30 @@ __device__ __forceinline__ void observe_block(const EcDev& d, const LaneId& L, u
             }
         }
     }
+    if (s_fullbits) {
+        const u64 ball = __ballot(L.valid && full);
+        if (L.valid && L.node == 0)
+            s_fullbits[L.env_local] = (ball >> (threadIdx.x & 63u)) & (N >= 64 ? ~0ull : (1ull << N) - 1ull);
+    }
     __syncthreads();
     const int64_t env0 = (int64_t)blockIdx.x * epb;
     const int64_t nenv = (d.B - env0) < epb ? (d.B - env0) : epb;
     if (avail) {
-        if (L.valid) {
-            // any adjacent (or own) queue with room?  adj rows are bit masks when N <= 64
-            u32 any = 0;
-            const u32* full = s_full + L.env_local * N;
-            if (d.adj_bits) {
-                const u64 row = d.adj_bits[L.node];
-                for (int j = 0; j < N; j++) any |= (((row >> j) & 1ull) && !full[j]) ? 1u : 0u;
-            } else {
-                for (int j = 0; j < N; j++) any |= (d.adj[L.node * A + j] && !full[j]) ? 1u : 0u;
+        if (!s_fullbits) {
+            if (L.valid) {
+                // any adjacent (or own) queue with room?  adj rows are bit masks when N <= 64
+                u32 any = 0;
+                const u32* fl = s_full + L.env_local * N;
+                if (d.adj_bits) {
+                    const u64 row = d.adj_bits[L.node];
+                    for (int j = 0; j < N; j++) any |= (((row >> j) & 1ull) && !fl[j]) ? 1u : 0u;
+                } else {
+                    for (int j = 0; j < N; j++) any |= (d.adj[L.node * A + j] && !fl[j]) ? 1u : 0u;
+                }
+                s_any[li] = any;
             }
-            s_any[li] = any;
+            __syncthreads();
         }
-        __syncthreads();
         const int total = (int)nenv * N * A;
         int32_t* out = avail + env0 * N * A;
         for (int idx = tid; idx < total; idx += blockDim.x) {
@@ -761,8 +804,13 @@ __device__ __forceinline__ void observe_block(const EcDev& d, const LaneId& L, u
             const int el = (int)fdiv((u32)t, d.divN), i = t - el * N;
             int v;
             if (s_hasnew[t]) {
-                const bool adjacent = d.adj_bits ? ((d.adj_bits[i] >> j) & 1ull) : (j < N && d.adj[i * A + j]);
-                v = (j < N) ? ((adjacent && !s_full[el * N + j]) || (!s_any[t] && j == i)) : 0;
+                if (s_fullbits) {
+                    const u64 room = d.adj_bits[i] & ~s_fullbits[el];  // adjacent queues with room
+                    v = (j < N) ? (int)((room >> j) & 1ull) | (int)(!room && j == i) : 0;
+                } else {
+                    const bool adjacent = d.adj_bits ? ((d.adj_bits[i] >> j) & 1ull) : (j < N && d.adj[i * A + j]);
+                    v = (j < N) ? ((adjacent && !s_full[el * N + j]) || (!s_any[t] && j == i)) : 0;
+                }
             } else {
                 v = (j == N);
             }
@@ -796,7 +844,7 @@ __global__ void k_observe(EcDev d, float* __restrict__ obs, int32_t* __restrict_
         // get_waiting_time, edge_node.py:99-104 (current_execute_time is 0 for every waiting task)
         for (u32 j = 0; j < wq_len; j++) w = dadd(w, d.wqe[(size_t)j * d.P + L.lane]);
     }
-    observe_block(d, L, wq_len, w, has_new, newt, obs, avail, s_full, s_hasnew, s_any, s_obs);
+    observe_block(d, L, wq_len, w, has_new, newt, obs, avail, s_full, s_hasnew, s_any, s_obs, nullptr);
 }
 
 // LDS carve-up of k_step; all per-lane arrays are [slot][NT], NT = active lanes of the block
@@ -816,9 +864,10 @@ struct StepLds {
     double* ct;      // [NT]
     u32* cnt;        // [4][NT]
     double* tu;      // [RB_TASK][NT] the step's task-stream doubles (producer -> consumer)
+    u64* fullbits;   // [NT] (one word per env used) "queue full" flags of an env's nodes, for the fused observation
     u32* rc;         // [RC_N][NT] RNG cursors and the producer/consumer hand-off (RC_*)
 };
-enum { RC_FPOS, RC_FAHEAD, RC_TPOS, RC_TAHEAD, RC_FDELTA, RC_TDELTA, RC_DONE, RC_NX, RC_N };
+enum { RC_FPOS, RC_FAHEAD, RC_TPOS, RC_TAHEAD, RC_FDELTA, RC_TDELTA, RC_DONE, RC_NX, RC_STAGED, RC_N };
 __host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int capW) {
     size_t b = 0;
     b += sizeof(double) * ACC_LDS;
@@ -827,7 +876,7 @@ __host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int
     b += (size_t)NT * DMAX * (32 + 5 * 4);
     b += (size_t)NT * (RB_FAIL + 1) * 4;
     b += (size_t)NT * (8 + 8 + 16);
-    b += (size_t)NT * (RB_TASK * 8 + RC_N * 4);
+    b += (size_t)NT * (RB_TASK * 8 + RC_N * 4 + 8);
     return b + 64;
 }
 
@@ -849,13 +898,19 @@ __device__ __forceinline__ u64 policy_hash(u64 seed, u64 counter, u64 rows, u64 
 
 #ifdef EC_STAMPS
 #define EC_STAMP(i)                                                                           \
-    do {                                                                                      \
-        __syncthreads();                                                                      \
+    do {  /* the timeline of wave 0; no barrier, which would serialise the producer wave */  \
         if (threadIdx.x == 0 && d.stamps) d.stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#define EC_STAMP_P(i)                                                                         \
+    do {  /* the producer wave's timeline */                                                  \
+        if ((int)threadIdx.x == d.nmain && d.stamps) d.stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
     } while (0)
 #else
 #define EC_STAMP(i) \
     do {            \
+    } while (0)
+#define EC_STAMP_P(i) \
+    do {              \
     } while (0)
 #endif
 
@@ -863,7 +918,7 @@ __device__ __forceinline__ u64 policy_hash(u64 seed, u64 counter, u64 rows, u64 
 // KMAX >= k and DMAX >= max in-degree are compile-time so that the executing slots and the receiving-queue
 // scalars live in registers and the per-mini-slot work is branch-free except for events.
 template <int KMAX, int DMAX>
-__global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(EcDev d, const int64_t* __restrict__ actions, float* __restrict__ reward,
+__global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict__ actions, float* __restrict__ reward,
                                               uint8_t* __restrict__ terminated, int32_t* __restrict__ counters,
                                               float* __restrict__ completion_time, float* __restrict__ next_obs,
                                               int32_t* __restrict__ next_avail, StepPolicy pol) {
@@ -886,6 +941,7 @@ __global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(
         S.rew = reinterpret_cast<double*>(p);    p += (size_t)NT * 8;
         S.ct = reinterpret_cast<double*>(p);     p += (size_t)NT * 8;
         S.tu = reinterpret_cast<double*>(p);     p += (size_t)NT * RB_TASK * 8;
+        S.fullbits = reinterpret_cast<u64*>(p);  p += (size_t)NT * 8;
         S.fa = reinterpret_cast<u32*>(p);        p += (size_t)NT * (RB_FAIL + 1) * 4;
         S.rqhs = reinterpret_cast<u32*>(p);      p += (size_t)NT * DMAX * 4;
         S.rqhead = reinterpret_cast<u32*>(p);    p += (size_t)NT * DMAX * 4;
@@ -897,11 +953,6 @@ __global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(
     }
     Lut lut{d, (lds_cdouble_ptr)S.acc, 0u};
 
-    {  // block-shared low part of the tick LUT
-        const int nacc = d.maxTicks + 1 < ACC_LDS ? d.maxTicks + 1 : ACC_LDS;
-        for (int i = threadIdx.x; i < nacc; i += blockDim.x) S.acc[i] = d.acc[i];
-    }
-
     // Two roles.  The main lanes (threads < d.nmain) run the env logic and only CONSUME random words.  The RNG
     // producer lanes regenerate the Mersenne-Twister states and stage the step's draws: a wave of their own
     // when the block was launched with more than d.nmain threads (its memory latency then overlaps the main
@@ -911,6 +962,16 @@ __global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(
     const LaneId R = has_producers ? lane_id(d, d.nmain) : L;
     const bool producer_wave = has_producers ? (int)threadIdx.x >= d.nmain : true;  // wave-uniform
     const int tid = L.lidx;  // slot of this main lane in the per-lane LDS arrays
+    double lut_lo[ACC_LDS / 64];  // block-shared low part of the tick LUT: loaded by the producer lanes with their
+    if (producer_wave) {          // first round of loads, stored to LDS before the first barrier
+        const int p0 = has_producers ? (int)threadIdx.x - d.nmain : (int)threadIdx.x;
+        const int np = has_producers ? (int)blockDim.x - d.nmain : (int)blockDim.x;
+#pragma unroll
+        for (int i = 0; i < ACC_LDS / 64; i++) {
+            const int a = p0 + i * np;
+            lut_lo[i] = d.acc[a <= d.maxTicks ? a : d.maxTicks];
+        }
+    }
     const int64_t lane = L.lane;
     const int node = L.node;
     EC_STAMP(0);
@@ -964,47 +1025,119 @@ __global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(
         const u64 me = d.thr_exec_m[node];
         exA_thr = (u32)(me >> 26);
         cap = d.cap[node];
-        if (has_new) newt = load_rec(d.newt + lane);
-        if (buf.len > 0) buf.head_rec = load_rec(d.buf + (size_t)buf.head * P + lane);
-        if (has_new && action >= 0 && action < N && action != node) {
-            slot = d.slot_of[node * N + (int)action];
-            rate = d.rate[node * N + (int)action];
+        // Second round of loads: every address the scalars above determine, issued before the first is consumed
+        // (into registers first, LDS afterwards), so that the lane's chain pays one memory round trip for the
+        // lot rather than one per queue.  The receiving-queue headers go first because the head records (third
+        // round) hang off them.  Every block of the launch does this at the same time: the burst is bandwidth
+        // bound at 4096 envs (3.8 us at 1024 envs, 6 us at 4096), so only live slots are loaded.
+        u32 ql[DMAX], qh[DMAX], qa[DMAX], qs[DMAX];
+        u64 ml[DMAX];
+#pragma unroll
+        for (int s = 0; s < DMAX; s++) {
+            const size_t so = (size_t)s * P + lane;
+            ql[s] = qh[s] = qa[s] = qs[s] = 0;
+            ml[s] = 0;
+            if (s < deg) {
+                ql[s] = d.rq_len[so];
+                qh[s] = d.rq_head[so];
+                qa[s] = d.rq_arrive[so];
+                qs[s] = d.rq_hstart[so];
+                ml[s] = d.thr_link_m[node * D + s];
+            }
         }
-        for (u32 j = 0; j < wq_len; j++) {
+        {
+            const bool off = has_new && action >= 0 && action < N && action != node;
+            const int ai = node * N + (off ? (int)action : node);
+            const int slot_l = d.slot_of[ai];
+            const double rate_l = d.rate[ai];
+            const Rec newt_l = load_rec(d.newt + lane);
+            const Rec head_l = load_rec(d.buf + (size_t)buf.head * P + lane);
+            if (off) {
+                slot = slot_l;
+                rate = rate_l;
+            }
+            if (has_new) newt = newt_l;
+            if (buf.len > 0) buf.head_rec = head_l;
+        }
+        u64 exa[KMAX], exc[KMAX];
+        double exb[KMAX];
+#pragma unroll
+        for (int s = 0; s < KMAX; s++) {
+            const size_t eo = (size_t)s * P + lane;
+            exa[s] = exc[s] = 0;
+            exb[s] = 0.0;
+            if ((u32)s < ex_n) {
+                exa[s] = d.exA[eo];
+                exb[s] = d.exB[eo];
+                exc[s] = d.exC[eo];
+            }
+        }
+        constexpr int WB = 8;  // waiting-queue entries per batch of loads
+        uint4 wm[WB];
+        double we[WB];
+#pragma unroll
+        for (int j = 0; j < WB; j++) {
+            const size_t wo = (size_t)j * P + lane;
+            wm[j] = make_uint4(0, 0, 0, 0);
+            we[j] = 0.0;
+            if ((u32)j < wq_len) {
+                wm[j] = d.wqm[wo];
+                we[j] = d.wqe[wo];
+            }
+        }
+        // third round: the head record of each receiving queue
+        uint4 q0[DMAX], q1[DMAX];
+#pragma unroll
+        for (int s = 0; s < DMAX; s++) {
+            q0[s] = q1[s] = make_uint4(0, 0, 0, 0);
+            if (s < deg && ql[s] > 0) {
+                const uint4* q = reinterpret_cast<const uint4*>(d.rq + ((size_t)s * d.capR + qh[s]) * P + lane);
+                q0[s] = q[0];
+                q1[s] = q[1];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KMAX; s++) {
+            if ((u32)s < ex_n) {
+                exw[s] = (u32)exa[s];
+                exh[s] = (u32)(exa[s] >> 32);
+                exT[s] = exb[s];
+            }
+        }
+        // consume
+#pragma unroll
+        for (int s = 0; s < DMAX; s++) {
+            if (s < deg) {
+                S.rqlen[s * NT + tid] = ql[s];
+                S.rqarr[s * NT + tid] = qa[s];
+                S.rqhead[s * NT + tid] = qh[s];
+                S.rqhs[s * NT + tid] = qs[s];
+                S.rqdirty[s * NT + tid] = 0;
+                lkA[s] = (u32)(ml[s] >> 26);
+            }
+            // unconditional (the slot exists for every s < DMAX; an unused one is never read): under the condition
+            // the compiler sinks each load to its store, one waited-for round trip per queue
+            S.rqrec[(s * 2 + 0) * NT + tid] = q0[s];
+            S.rqrec[(s * 2 + 1) * NT + tid] = q1[s];
+        }
+#pragma unroll
+        for (int s = 0; s < KMAX; s++)
+            if ((u32)s < ex_n) S.exC[s * NT + tid] = exc[s];
+#pragma unroll
+        for (int j = 0; j < WB; j++) {
+            if ((u32)j < wq_len) {
+                S.wqm[j * NT + tid] = wm[j];
+                S.wqe[j * NT + tid] = we[j];
+                const u32 da = wmeta_drop_at(wm[j]);
+                wq_min = da < wq_min ? da : wq_min;
+            }
+        }
+        for (u32 j = WB; j < wq_len; j++) {  // a queue deeper than one batch
             const uint4 m = d.wqm[(size_t)j * P + lane];
             S.wqm[j * NT + tid] = m;
             S.wqe[j * NT + tid] = d.wqe[(size_t)j * P + lane];
             const u32 da = wmeta_drop_at(m);
             wq_min = da < wq_min ? da : wq_min;
-        }
-#pragma unroll
-        for (int s = 0; s < KMAX; s++) {
-            if ((u32)s < ex_n) {
-                const u64 a = d.exA[(size_t)s * P + lane];
-                exw[s] = (u32)a;
-                exh[s] = (u32)(a >> 32);
-                exT[s] = d.exB[(size_t)s * P + lane];
-                S.exC[s * NT + tid] = d.exC[(size_t)s * P + lane];
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < DMAX; s++) {
-            if (s < deg) {
-                const size_t so = (size_t)s * P + lane;
-                const u32 ql = d.rq_len[so], qh = d.rq_head[so];
-                S.rqlen[s * NT + tid] = ql;
-                S.rqarr[s * NT + tid] = d.rq_arrive[so];
-                S.rqhead[s * NT + tid] = qh;
-                S.rqhs[s * NT + tid] = d.rq_hstart[so];
-                S.rqdirty[s * NT + tid] = 0;
-                const u64 ml = d.thr_link_m[node * D + s];
-                lkA[s] = (u32)(ml >> 26);
-                if (ql > 0) {
-                    const uint4* q = reinterpret_cast<const uint4*>(d.rq + ((size_t)s * d.capR + qh) * P + lane);
-                    S.rqrec[(s * 2 + 0) * NT + tid] = q[0];
-                    S.rqrec[(s * 2 + 1) * NT + tid] = q[1];
-                }
-            }
         }
     }
     // producer, part 1: this step's task doubles and the failure window, straight from the words regenerated
@@ -1014,19 +1147,55 @@ __global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(
         const size_t tl = (size_t)R.lane, fl = (size_t)P + (size_t)R.lane;
         const u32 tpos = d.rng_pos[tl], tah = d.rng_ahead[tl], fpos = d.rng_pos[fl], fah = d.rng_ahead[fl];
         RngTask pt;
-        pt.open(d.mt + tl * MT_STRIDE, tpos, tah);
+        RngFail pf;
+        if (tah >= (u32)AHEAD_TASK && fah >= (u32)AHEAD_FAIL) {
+            // the common case: both streams are regenerated far enough; every load is issued before the first
+            // word is tempered, so the whole window costs one memory round trip
+            const u32* tw = d.mt + tl * MT_STRIDE + tpos;  // wrap-free thanks to the mirror
+            const u32* fw = d.mt + fl * MT_STRIDE + fpos;
+            // (the first RB_EARLY draws now; the rest of the window after the second barrier, off the burst of
+            // loads with which every block of the launch starts)
+            u32x4 fv[RB_EARLY / 2];
+#pragma unroll
+            for (int i = 0; i < RB_EARLY / 2; i++) fv[i] = *reinterpret_cast<const u32x4*>(fw + 4 * i);
+            const u32x4 t0 = *reinterpret_cast<const u32x4*>(tw), t1 = *reinterpret_cast<const u32x4*>(tw + 4);
+#pragma unroll
+            for (int i = 0; i < RB_EARLY / 2; i++) {
+                S.fa[(2 * i) * NT + ri] = mt_temper(fv[i].x) >> 5;
+                S.fa[(2 * i + 1) * NT + ri] = mt_temper(fv[i].z) >> 5;
+            }
+            S.rc[RC_STAGED * NT + ri] = (u32)RB_EARLY;
+            pt.u0 = mt_to_double(t0.x, t0.y);
+            pt.u1 = mt_to_double(t0.z, t0.w);
+            pt.u2 = mt_to_double(t1.x, t1.y);
+            pt.u3 = mt_to_double(t1.z, t1.w);
+            pt.ahead = tah;
+            pf.ahead = fah;
+        } else {
+            pt.open(d.mt + tl * MT_STRIDE, tpos, tah);
+            pf.open(d.mt + fl * MT_STRIDE, fpos, fah, S.fa + ri, NT, (u32)RB_FAIL);
+            S.rc[RC_STAGED * NT + ri] = (u32)RB_FAIL;
+        }
         S.tu[0 * NT + ri] = pt.u0;
         S.tu[1 * NT + ri] = pt.u1;
         S.tu[2 * NT + ri] = pt.u2;
         S.tu[3 * NT + ri] = pt.u3;
-        RngFail pf;
-        pf.open(d.mt + fl * MT_STRIDE, fpos, fah, S.fa + ri, NT, (u32)RB_FAIL);
         S.rc[RC_FPOS * NT + ri] = fpos;
         S.rc[RC_FAHEAD * NT + ri] = pf.ahead;
         S.rc[RC_TPOS * NT + ri] = tpos;
         S.rc[RC_TAHEAD * NT + ri] = pt.ahead;
         S.rc[RC_DONE * NT + ri] = 0;
     }
+    if (producer_wave) {
+        const int p0 = has_producers ? (int)threadIdx.x - d.nmain : (int)threadIdx.x;
+        const int np = has_producers ? (int)blockDim.x - d.nmain : (int)blockDim.x;
+#pragma unroll
+        for (int i = 0; i < ACC_LDS / 64; i++) {
+            const int a = p0 + i * np;
+            if (a < ACC_LDS) S.acc[a] = lut_lo[i];
+        }
+    }
+    EC_STAMP_P(11);
     __syncthreads();
     EC_STAMP(1);
 
@@ -1107,6 +1276,20 @@ __global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(
             fah = S.rc[RC_FAHEAD * NT + ri];
             tpos = S.rc[RC_TPOS * NT + ri];
             tah = S.rc[RC_TAHEAD * NT + ri];
+            if (S.rc[RC_STAGED * NT + ri] < (u32)RB_FAIL) {  // the rest of the window (fah >= AHEAD_FAIL here)
+                const u32* fw = d.mt + ((size_t)P + (size_t)R.lane) * MT_STRIDE + fpos;
+                u32x4 fv[(RB_FAIL - RB_EARLY) / 2];
+#pragma unroll
+                for (int i = 0; i < (RB_FAIL - RB_EARLY) / 2; i++)
+                    fv[i] = *reinterpret_cast<const u32x4*>(fw + 4 * (i + RB_EARLY / 2));
+#pragma unroll
+                for (int i = 0; i < (RB_FAIL - RB_EARLY) / 2; i++) {
+                    S.fa[(RB_EARLY + 2 * i) * NT + ri] = mt_temper(fv[i].x) >> 5;
+                    S.fa[(RB_EARLY + 2 * i + 1) * NT + ri] = mt_temper(fv[i].z) >> 5;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __hip_atomic_store(&S.rc[RC_STAGED * NT + ri], (u32)RB_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             u32 n_ne = 0;
             const int rdeg = d.deg[R.node];
             for (int s = 0; s < rdeg; s++) n_ne += S.rqlen[s * NT + ri] > 0 ? 1u : 0u;
@@ -1124,6 +1307,7 @@ __global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the regenerated words before the flag
             __hip_atomic_store(&S.rc[RC_DONE * NT + ri], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        EC_STAMP_P(12);
     }
 
     // ---------------------------------------------------------------- failure-stream window
@@ -1143,7 +1327,7 @@ __global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(
         const u32 n_ex = ex_n + wq_len < (u32)d.k ? ex_n + wq_len : (u32)d.k;
         draw_bound = (u32)d.S * (n_ex + n_ne);
         frng.attach(d.mt + ((size_t)P + lane) * MT_STRIDE, S.rc[RC_FPOS * NT + tid], S.rc[RC_FAHEAD * NT + tid],
-                    S.fa + tid, NT, (u32)RB_FAIL);
+                    S.fa + tid, NT, S.rc[RC_STAGED * NT + tid]);
     }
     bool f_synced = false;  // frng.ahead includes the producer's part-2 regeneration
 
@@ -1190,6 +1374,14 @@ __global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(
             u32 n_ne = 0;
 #pragma unroll
             for (int s = 0; s < DMAX; s++) n_ne += rql[s] > 0 ? 1u : 0u;
+            if (frng.idx + ex_n + n_ne > frng.staged && frng.staged < (u32)RB_FAIL && frng.used == 0) {
+                // the producer is still filling this window: it has been at it since the second barrier
+                while (__hip_atomic_load(&S.rc[RC_STAGED * NT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                       (u32)RB_FAIL)
+                    __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                frng.staged = RB_FAIL;
+            }
             if (frng.idx + ex_n + n_ne > frng.staged) {
                 if (!f_synced) {
                     // the producer may still be regenerating this stream: wait for it (it never waits for us)
@@ -1387,23 +1579,27 @@ __global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(
         S.cnt[3 * NT + tid] = n_fail;
     }
     __syncthreads();
-    if (L.valid && node == 0) {
+    // the per-env sums are the producer lanes' job when they have a wave of their own (it is idle by now)
+    if (R.valid && R.node == 0) {
+        const int ri = R.lidx;
+        const u32 tick0 = has_producers ? d.tick[R.env] : c0;
+        const u32 steps0 = has_producers ? d.total_steps[R.env] : steps_before;
+        const u32 step_now = d.cur_step[R.env] + 1;  // :125
         double r = 0.0, t = 0.0;
         u32 c4[4] = {0, 0, 0, 0};
         for (int i = 0; i < N; i++) {  // node order, as the reference sums
-            r = dadd(r, S.rew[tid + i]);
-            t = dadd(t, S.ct[tid + i]);
+            r = dadd(r, S.rew[ri + i]);
+            t = dadd(t, S.ct[ri + i]);
 #pragma unroll
-            for (int q = 0; q < 4; q++) c4[q] += S.cnt[q * NT + tid + i];
+            for (int q = 0; q < 4; q++) c4[q] += S.cnt[q * NT + ri + i];
         }
-        const u32 step_now = d.cur_step[L.env] + 1;  // :125
-        d.cur_step[L.env] = step_now;
-        d.total_steps[L.env] = steps_before + 1;
-        d.tick[L.env] = c0 + (u32)d.S;
-        if (reward) reward[L.env] = (float)r;
-        if (completion_time) completion_time[L.env] = (float)t;
-        if (counters) *reinterpret_cast<int4*>(counters + 4 * L.env) = make_int4((int)c4[0], (int)c4[1], (int)c4[2], (int)c4[3]);
-        if (terminated) terminated[L.env] = step_now >= (u32)d.T ? 1 : 0;  // :139-142
+        d.cur_step[R.env] = step_now;
+        d.total_steps[R.env] = steps0 + 1;
+        d.tick[R.env] = tick0 + (u32)d.S;
+        if (reward) reward[R.env] = (float)r;
+        if (completion_time) completion_time[R.env] = (float)t;
+        if (counters) *reinterpret_cast<int4*>(counters + 4 * R.env) = make_int4((int)c4[0], (int)c4[1], (int)c4[2], (int)c4[3]);
+        if (terminated) terminated[R.env] = step_now >= (u32)d.T ? 1 : 0;  // :139-142
     }
 
     EC_STAMP(5);
@@ -1481,12 +1677,14 @@ __global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(
 #else
     if (next_obs || next_avail) {
 #endif
-        __syncthreads();  // the failure-stream window is dead: reuse it as observation scratch
+        // the failure-stream window is dead since the barrier of phase C: reuse it as observation scratch
         u32* s_full = S.fa;
         u32* s_hasnew = s_full + NT;
         u32* s_any = s_hasnew + NT;
         float* s_obs = reinterpret_cast<float*>(s_any + NT);
-        observe_block(d, L, wq_len, wait_sum, has_new, nnew, next_obs, next_avail, s_full, s_hasnew, s_any, s_obs);
+        u64* s_fullbits = (d.epw > 0 && d.adj_bits) ? S.fullbits : nullptr;
+        observe_block(d, L, wq_len, wait_sum, has_new, nnew, next_obs, next_avail, s_full, s_hasnew, s_any, s_obs,
+                      s_fullbits);
         if (pol.next_actions) {
             // s_full / s_hasnew / s_any still hold the mask's ingredients (edge_node.py:179-197)
             // every env of the handle has taken the same number of steps: a launch counter without atomics
@@ -1499,7 +1697,11 @@ __global__ void __launch_bounds__(256, (KMAX <= 4 && DMAX <= 4) ? 3 : 2) k_step(
                     if (d.adj_bits) {
                         // the mask as bits: neighbours and self with room, else self (edge_node.py:179-197)
                         u64 fullbits = 0;
-                        for (int j = 0; j < N; j++) fullbits |= (u64)(full[j] != 0) << j;
+                        if (s_fullbits) {
+                            fullbits = s_fullbits[L.env_local];
+                        } else {
+                            for (int j = 0; j < N; j++) fullbits |= (u64)(full[j] != 0) << j;
+                        }
                         u64 m = d.adj_bits[node] & ~fullbits;
                         if (!m) m = 1ull << node;
                         const int cnt = __popcll(m);

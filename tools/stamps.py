@@ -22,7 +22,7 @@ act = th.empty(B, 10, dtype=th.int64, device=env.device)
 env.reset()
 env.observe()
 names = ["entry->staged", "offload", "fail window", "tick0", "tick1", "ticks 2..9", "reduce", "generate+writeback",
-         "coop refill", "observe"]
+         "(unused)", "observe", "producer: window+doubles (from entry)", "producer: regeneration (from offload end)"]
 acc = []
 for t in range(160):
     env.random_actions(seed=0, counter=t, out=act)
@@ -35,6 +35,7 @@ for t in range(160):
         s = buf[: n.value * 16].reshape(n.value, 16).astype(np.int64)
         seg = np.stack([s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 9] - s[:, 3], s[:, 10] - s[:, 9],
                         s[:, 4] - s[:, 10], s[:, 5] - s[:, 4], s[:, 6] - s[:, 5], s[:, 7] - s[:, 6], s[:, 8] - s[:, 7]], 1)
+        seg = np.concatenate([seg, np.stack([s[:, 11] - s[:, 0], s[:, 12] - s[:, 2]], 1)], 1)
         span = (s[:, 8].max() - s[:, 0].min())
         acc.append((seg.mean(0), seg.max(0), span, (s[:, 8] - s[:, 0]).mean(), s[:, 0].max() - s[:, 0].min()))
 m = np.mean([a[0] for a in acc], 0) / 100.0  # wall_clock64 ticks at 100 MHz -> us
@@ -42,4 +43,4 @@ mx = np.mean([a[1] for a in acc], 0) / 100.0
 print("epb", env.info_geometry()["envs_per_block"], "blocks span %.1f us, mean block %.1f us, start skew %.1f us" % (
     np.mean([a[2] for a in acc]) / 100.0, np.mean([a[3] for a in acc]) / 100.0, np.mean([a[4] for a in acc]) / 100.0))
 for nm, a, b in zip(names, m, mx):
-    print("  %-20s mean %6.2f us   max-block %6.2f us" % (nm, a, b))
+    print("  %-42s mean %6.2f us   max-block %6.2f us" % (nm, a, b))
