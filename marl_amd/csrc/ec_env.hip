@@ -48,6 +48,7 @@ constexpr int AHEAD_FAIL = 2 * RB_FAIL;  // words regenerated ahead of the failu
 constexpr int RB_TASK = 4;   // doubles of the task stream staged per refill (binomial + id + size + cycles)
 constexpr int AHEAD_TASK = 2 * RB_TASK;
 constexpr int RB_EARLY = 16;  // draws of the window staged before the step's first barrier; the rest follows during the mini-slots
+constexpr u32 STAGED_FINAL = 0x80000000u;  // flag on the window's staged count: the producer will add no more
 constexpr int AHEAD_MAX = 512;  // cap of the words kept regenerated ahead (a 64-word batch must not lap the cursor)
 constexpr int ACC_LDS = 256; // low part of the tick LUT kept in LDS
 
@@ -1174,7 +1175,7 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         } else {
             pt.open(d.mt + tl * MT_STRIDE, tpos, tah);
             pf.open(d.mt + fl * MT_STRIDE, fpos, fah, S.fa + ri, NT, (u32)RB_FAIL);
-            S.rc[RC_STAGED * NT + ri] = (u32)RB_FAIL;
+            S.rc[RC_STAGED * NT + ri] = (u32)RB_FAIL | STAGED_FINAL;
         }
         S.tu[0 * NT + ri] = pt.u0;
         S.tu[1 * NT + ri] = pt.u1;
@@ -1276,25 +1277,31 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
             fah = S.rc[RC_FAHEAD * NT + ri];
             tpos = S.rc[RC_TPOS * NT + ri];
             tah = S.rc[RC_TAHEAD * NT + ri];
-            if (S.rc[RC_STAGED * NT + ri] < (u32)RB_FAIL) {  // the rest of the window (fah >= AHEAD_FAIL here)
-                const u32* fw = d.mt + ((size_t)P + (size_t)R.lane) * MT_STRIDE + fpos;
-                u32x4 fv[(RB_FAIL - RB_EARLY) / 2];
-#pragma unroll
-                for (int i = 0; i < (RB_FAIL - RB_EARLY) / 2; i++)
-                    fv[i] = *reinterpret_cast<const u32x4*>(fw + 4 * (i + RB_EARLY / 2));
-#pragma unroll
-                for (int i = 0; i < (RB_FAIL - RB_EARLY) / 2; i++) {
-                    S.fa[(RB_EARLY + 2 * i) * NT + ri] = mt_temper(fv[i].x) >> 5;
-                    S.fa[(RB_EARLY + 2 * i + 1) * NT + ri] = mt_temper(fv[i].z) >> 5;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __hip_atomic_store(&S.rc[RC_STAGED * NT + ri], (u32)RB_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
             u32 n_ne = 0;
             const int rdeg = d.deg[R.node];
             for (int s = 0; s < rdeg; s++) n_ne += S.rqlen[s * NT + ri] > 0 ? 1u : 0u;
             const u32 nx = S.rc[RC_NX * NT + ri];
             const u32 bound = (u32)d.S * ((nx < (u32)d.k ? nx : (u32)d.k) + n_ne);  // the step's draw bound, as below
+            if (S.rc[RC_STAGED * NT + ri] < (u32)RB_FAIL) {
+                // the rest of the window, as far as this step can draw (fah >= AHEAD_FAIL here)
+                const u32 upto = bound < (u32)RB_FAIL ? bound : (u32)RB_FAIL;
+                const u32* fw = d.mt + ((size_t)P + (size_t)R.lane) * MT_STRIDE + fpos;
+                u32x4 fv[(RB_FAIL - RB_EARLY) / 2];
+#pragma unroll
+                for (int i = 0; i < (RB_FAIL - RB_EARLY) / 2; i++) {
+                    fv[i] = u32x4{0, 0, 0, 0};
+                    if ((u32)(RB_EARLY + 2 * i) < upto) fv[i] = *reinterpret_cast<const u32x4*>(fw + 4 * (i + RB_EARLY / 2));
+                }
+#pragma unroll
+                for (int i = 0; i < (RB_FAIL - RB_EARLY) / 2; i++) {
+                    S.fa[(RB_EARLY + 2 * i) * NT + ri] = mt_temper(fv[i].x) >> 5;
+                    S.fa[(RB_EARLY + 2 * i + 1) * NT + ri] = mt_temper(fv[i].z) >> 5;
+                }
+                const u32 staged = upto < (u32)RB_EARLY ? (u32)RB_EARLY : (upto + 1u) & ~1u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __hip_atomic_store(&S.rc[RC_STAGED * NT + ri], staged | STAGED_FINAL, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             want_f = (u32)AHEAD_FAIL + 2u * bound;
             want_f = want_f < (u32)AHEAD_MAX ? want_f : (u32)AHEAD_MAX;
         }
@@ -1314,6 +1321,7 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
     // Within a step no queue gains a task after phase A, so this bounds the lane's draws: per mini-slot at most
     // min(k, executing + waiting) execution draws and one draw per non-empty receiving queue.
     u32 draw_bound = 0;
+    bool f_final = true;  // the producer has staged all it is going to stage of the first window
     if (L.valid) {
         u32 n_ne = 0;
 #pragma unroll
@@ -1327,7 +1335,8 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
         const u32 n_ex = ex_n + wq_len < (u32)d.k ? ex_n + wq_len : (u32)d.k;
         draw_bound = (u32)d.S * (n_ex + n_ne);
         frng.attach(d.mt + ((size_t)P + lane) * MT_STRIDE, S.rc[RC_FPOS * NT + tid], S.rc[RC_FAHEAD * NT + tid],
-                    S.fa + tid, NT, S.rc[RC_STAGED * NT + tid]);
+                    S.fa + tid, NT, S.rc[RC_STAGED * NT + tid] & ~STAGED_FINAL);
+        f_final = (S.rc[RC_STAGED * NT + tid] & STAGED_FINAL) != 0;
     }
     bool f_synced = false;  // frng.ahead includes the producer's part-2 regeneration
 
@@ -1374,13 +1383,15 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
             u32 n_ne = 0;
 #pragma unroll
             for (int s = 0; s < DMAX; s++) n_ne += rql[s] > 0 ? 1u : 0u;
-            if (frng.idx + ex_n + n_ne > frng.staged && frng.staged < (u32)RB_FAIL && frng.used == 0) {
+            if (frng.idx + ex_n + n_ne > frng.staged && !f_final) {
                 // the producer is still filling this window: it has been at it since the second barrier
-                while (__hip_atomic_load(&S.rc[RC_STAGED * NT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
-                       (u32)RB_FAIL)
+                u32 st;
+                while (!((st = __hip_atomic_load(&S.rc[RC_STAGED * NT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) &
+                         STAGED_FINAL))
                     __builtin_amdgcn_s_sleep(2);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                frng.staged = RB_FAIL;
+                frng.staged = st & ~STAGED_FINAL;
+                f_final = true;
             }
             if (frng.idx + ex_n + n_ne > frng.staged) {
                 if (!f_synced) {
@@ -1391,6 +1402,9 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
                     frng.ahead += S.rc[RC_FDELTA * NT + tid];
                     f_synced = true;
                 }
+#ifdef EC_STAMPS
+                if (d.stamps) atomicAdd((unsigned long long*)&d.stamps[(size_t)blockIdx.x * 16 + 13], 1ull);
+#endif
                 const u32 left = draw_bound - (frng.used + frng.idx);  // the bound only shrinks as draws are spent
                 frng.restage(left < (u32)RB_FAIL ? left : (u32)RB_FAIL);
             }
