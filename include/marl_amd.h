@@ -125,6 +125,25 @@ int ec_step_random_policy(ec_handle h, const int64_t* actions, float* reward, ui
                           float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail,
                           uint64_t seed, uint64_t counter, int64_t* next_actions, void* stream);
 
+/* n_steps consecutive ec_step_random_policy calls in ONE launch: the env loop `while not done: a = random over
+ * avail; env.step(a)` of the reference (the uniform-random policy of action_selectors.py:6-8 driving
+ * edge_computing_env.py:84-143), e.g. one call per episode.  Results are identical to calling
+ * ec_step_random_policy n_steps times with next_actions fed back as actions (the parity tests compare the two);
+ * what it saves is the launch boundary: every block carries its envs through all steps, so there is no gap
+ * between steps and the blocks do not hit memory in lock step.
+ *   keep_history = 0: every step overwrites the same [B,...] outputs (what the n_steps calls would leave behind);
+ *                     next_actions may alias actions.
+ *   keep_history = 1: reward [n_steps,B], terminated [n_steps,B], counters [n_steps,B,4], completion_time
+ *                     [n_steps,B], next_obs [n_steps,B,N,9], next_avail [n_steps,B,N,N+1] and next_actions
+ *                     [n_steps,B,N] receive one slice per step (slice t = the outputs of step t; next_actions[t] is
+ *                     the action taken at step t+1).  NULL outputs are skipped; next_avail and next_actions are
+ *                     required.  hop_hist (cumulative) is copied once, after the last step.
+ * The caller keeps n_steps within the episode (the envs are not reset inside). */
+int ec_rollout_random_policy(ec_handle h, int32_t n_steps, int32_t keep_history, const int64_t* actions, float* reward,
+                             uint8_t* terminated, int32_t* counters, float* completion_time, int32_t* hop_hist,
+                             float* next_obs, int32_t* next_avail, uint64_t seed, uint64_t counter,
+                             int64_t* next_actions, void* stream);
+
 /* The expert of the GAIL / DGAIL runners for every env of the handle: OptimalAgent.get_current_optimal_action
  * (optimal/optimal_agent.py:102-120) = _conservative_action_selection at conservativeness 1.0 (:166-209) with the
  * reliability / time-margin / load / efficiency scores of :211-375, evaluated on the device state instead of walking

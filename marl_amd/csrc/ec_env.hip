@@ -165,6 +165,67 @@ struct EcDev {
     u64* stamps;    // [blocks][16] phase time stamps (EC_STAMPS diagnostic build only), else null
 };
 
+// A pointer that reaches a kernel inside a struct read from memory is generic to the compiler (flat loads and
+// stores); one that arrives as a kernel argument is known to be global.  The looping kernel reads its EcDev from
+// memory, so it passes every pointer member through the global address space (plus an offset of zero that the
+// compiler cannot see through) on its way back to a generic pointer: provenance the address-space inference uses.
+template <typename T>
+__device__ __forceinline__ T* as_global(T* p, size_t zero) {
+    typedef T __attribute__((address_space(1))) GT;
+    return (T*)((GT*)p + zero);  // the (opaque) offset keeps the two casts from cancelling
+}
+__device__ __forceinline__ void ec_dev_globalize(EcDev& d, size_t zero) {
+#define EC_G(f) d.f = as_global(d.f, zero)
+    EC_G(acc);
+    EC_G(cap);
+    EC_G(thr_exec_m);
+    EC_G(qlen);
+    EC_G(qthr);
+    EC_G(obs_const);
+    EC_G(bin_qn);
+    EC_G(bin_px2);
+    EC_G(bin_flip);
+    EC_G(deg);
+    EC_G(in_src);
+    EC_G(thr_link_m);
+    EC_G(slot_of);
+    EC_G(rate);
+    EC_G(adj);
+    EC_G(adj_bits);
+    EC_G(efr);
+    EC_G(tfr);
+    EC_G(cores);
+    EC_G(mt);
+    EC_G(rng_pos);
+    EC_G(rng_ahead);
+    EC_G(rng_cnt);
+    EC_G(has_new);
+    EC_G(newt);
+    EC_G(buf_head);
+    EC_G(buf_len);
+    EC_G(buf);
+    EC_G(wq_len);
+    EC_G(wqm);
+    EC_G(wqe);
+    EC_G(ex_n);
+    EC_G(exA);
+    EC_G(exB);
+    EC_G(exC);
+    EC_G(rq_head);
+    EC_G(rq_len);
+    EC_G(rq_arrive);
+    EC_G(rq_hstart);
+    EC_G(rq);
+    EC_G(n_off);
+    EC_G(cur_step);
+    EC_G(tick);
+    EC_G(total_steps);
+    EC_G(hop_hist);
+    EC_G(status);
+    EC_G(stamps);
+#undef EC_G
+}
+
 // ------------------------------------------------------------------------------------------ helpers
 __device__ __forceinline__ double dadd(double a, double b) { return __dadd_rn(a, b); }
 __device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a, b); }
@@ -888,6 +949,9 @@ constexpr u32 KIND_SUCCESS = 1u << 16;
 struct StepPolicy {
     u64 seed, counter;       // the draw uses counter + (steps this handle has taken, this one included)
     int64_t* next_actions;   // [B,N] or null (no policy)
+    // ec_rollout_random_policy: the kernel takes n_steps steps, each fed by the actions its predecessor drew.
+    // keep = 0: every step overwrites the same [B,...] outputs; keep = 1: outputs are [n_steps,B,...] histories.
+    int n_steps, keep;
 };
 
 __device__ __forceinline__ u64 policy_hash(u64 seed, u64 counter, u64 rows, u64 r) {
@@ -919,10 +983,10 @@ __device__ __forceinline__ u64 policy_hash(u64 seed, u64 counter, u64 rows, u64 
 // KMAX >= k and DMAX >= max in-degree are compile-time so that the executing slots and the receiving-queue
 // scalars live in registers and the per-mini-slot work is branch-free except for events.
 template <int KMAX, int DMAX>
-__global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict__ actions, float* __restrict__ reward,
-                                              uint8_t* __restrict__ terminated, int32_t* __restrict__ counters,
-                                              float* __restrict__ completion_time, float* __restrict__ next_obs,
-                                              int32_t* __restrict__ next_avail, StepPolicy pol) {
+__device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restrict__ actions, float* __restrict__ reward,
+                                          uint8_t* __restrict__ terminated, int32_t* __restrict__ counters,
+                                          float* __restrict__ completion_time, float* __restrict__ next_obs,
+                                          int32_t* __restrict__ next_avail, StepPolicy pol) {
     static_assert(RB_FAIL >= KMAX + DMAX, "failure window too small");
     static_assert(RB_FAIL * 4 >= 12 + 36, "observation scratch does not fit the failure window");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1746,18 +1810,60 @@ __global__ void __launch_bounds__(256) k_step(EcDev d, const int64_t* __restrict
     EC_STAMP(8);
 }
 
-typedef void (*step_fn)(EcDev, const int64_t*, float*, uint8_t*, int32_t*, float*, float*, int32_t*, StepPolicy);
-template <int KMAX>
+// One env step per launch (ec_step, ec_step_random_policy), or -- MULTI -- pol0.n_steps of them in one launch
+// (ec_rollout_random_policy): each block carries its own envs through all the steps, so there is no launch gap and
+// the blocks drift apart instead of hitting memory in lock step.  State goes through global memory between
+// iterations exactly as between launches; a block only ever re-reads what it wrote itself (workgroup-scope
+// ordering: the barrier).  The MULTI loop re-reads the geometry/pointer block from memory every iteration through
+// a pointer the compiler cannot see through: held in registers across the whole body instead, its ~150 words
+// double the spills of the step code.
+template <int KMAX, int DMAX, bool MULTI>
+__global__ void __launch_bounds__(256) k_step(EcDev d_arg, const EcDev* d_mem, const int64_t* actions0, float* reward0,
+                                              uint8_t* terminated0, int32_t* counters0, float* completion_time0,
+                                              float* next_obs0, int32_t* next_avail0, StepPolicy pol0) {
+    if (!MULTI) {
+        step_body<KMAX, DMAX>(d_arg, actions0, reward0, terminated0, counters0, completion_time0, next_obs0, next_avail0,
+                              pol0);
+        return;
+    }
+    for (int it = 0; it < pol0.n_steps; it++) {
+        size_t opaque = 0;  // an offset the compiler cannot see through: *dp is loaded anew in every iteration
+        asm volatile("" : "+s"(opaque));
+        const EcDev* dp = d_mem + opaque;
+        EcDev d;
+        {   // uniform words: into SGPRs (a plain copy would sit in ~150 VGPRs)
+            static_assert(sizeof(EcDev) % 4 == 0, "EcDev is copied word by word");
+            const u32* src = reinterpret_cast<const u32*>(dp);
+            u32* dst = reinterpret_cast<u32*>(&d);
+#pragma unroll
+            for (size_t i = 0; i < sizeof(EcDev) / 4; i++) dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
+        }
+        ec_dev_globalize(d, opaque);
+        const int64_t hs = pol0.keep ? (int64_t)it : 0;  // history slot of this iteration's outputs
+        StepPolicy pol = pol0;
+        pol.next_actions += hs * d.P;
+        step_body<KMAX, DMAX>(d, it == 0 ? actions0 : pol0.next_actions + (pol0.keep ? (int64_t)(it - 1) * d.P : 0),
+                              reward0 ? reward0 + hs * d.B : nullptr, terminated0 ? terminated0 + hs * d.B : nullptr,
+                              counters0 ? counters0 + hs * d.B * 4 : nullptr,
+                              completion_time0 ? completion_time0 + hs * d.B : nullptr,
+                              next_obs0 ? next_obs0 + hs * d.P * 9 : nullptr, next_avail0 + hs * d.P * d.A, pol);
+        __syncthreads();  // LDS is restaged, and this block's global writes are re-read
+    }
+}
+
+typedef void (*step_fn)(EcDev, const EcDev*, const int64_t*, float*, uint8_t*, int32_t*, float*, float*, int32_t*, StepPolicy);
+template <int KMAX, bool MULTI>
 step_fn pick_step_d(int D) {
-    if (D <= 4) return k_step<KMAX, 4>;
-    if (D <= 8) return k_step<KMAX, 8>;
+    if (D <= 4) return k_step<KMAX, 4, MULTI>;
+    if (D <= 8) return k_step<KMAX, 8, MULTI>;
     return nullptr;
 }
+template <bool MULTI>
 step_fn pick_step(int k, int D, int* kmax, int* dmax) {
     *dmax = D <= 4 ? 4 : 8;
-    if (k <= 4) return *kmax = 4, pick_step_d<4>(D);
-    if (k <= 8) return *kmax = 8, pick_step_d<8>(D);
-    if (k <= 12) return *kmax = 12, pick_step_d<12>(D);
+    if (k <= 4) return *kmax = 4, pick_step_d<4, MULTI>(D);
+    if (k <= 8) return *kmax = 8, pick_step_d<8, MULTI>(D);
+    if (k <= 12) return *kmax = 12, pick_step_d<12, MULTI>(D);
     return nullptr;
 }
 
@@ -1954,7 +2060,9 @@ struct ec_env {
     int threads_obs;  // block size of k_observe (the block's lanes, contiguous)
     int64_t blocks;
     size_t lds_step, lds_obs;
-    step_fn step;
+    step_fn step;        // one env step per launch
+    step_fn step_multi;  // the same kernel looping over steps (ec_rollout_random_policy)
+    EcDev* d_dev;        // device copy of `d` for the looping kernel
     int kmax, dmax;
     std::vector<void*> allocs;
     size_t state_bytes;
@@ -2168,7 +2276,8 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     //  * the RNG producer lanes get a wave of their own (one per 64 lanes of the block) when that still fits.
     // Candidates in order of preference: producers yes/no is tried per (envs per wave, main waves) pair, envs
     // per wave ascending, main waves ascending (more of them share one producer wave and one LUT copy).
-    h->step = pick_step(d.k, D, &h->kmax, &h->dmax);
+    h->step = pick_step<false>(d.k, D, &h->kmax, &h->dmax);
+    h->step_multi = pick_step<true>(d.k, D, &h->kmax, &h->dmax);
     if (!h->step) return ec::fail(EC_EINVAL, "k=%d / max in-degree %d exceed the compiled limits (12 / 8)", d.k, D);
     const void* fn = reinterpret_cast<const void*>(h->step);
     hipDeviceProp_t prop;
@@ -2243,9 +2352,14 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     h->lds_step = step_lds_bytes(epb * N, h->kmax, h->dmax, d.capW);
     if (h->lds_step > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_step);
     EC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
+    EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->step_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)h->lds_step));
 #ifdef EC_STAMPS
     EC_TRY(dev_alloc(h, &d.stamps, (size_t)h->blocks * 16, true));
 #endif
+
+    EC_TRY(dev_alloc(h, &h->d_dev, 1));
+    EC_HIP(hipMemcpy(h->d_dev, &d, sizeof(EcDev), hipMemcpyHostToDevice));
 
     const u32 ts = (u32)(cfg->task_seed + env_id_base), fs = (u32)(cfg->failure_seed + env_id_base);
     const int64_t gb = (d.P + 255) / 256;
@@ -2318,8 +2432,9 @@ static int step_impl(ec_handle h, const int64_t* actions, float* reward, uint8_t
                      float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail, StepPolicy pol,
                      void* stream) {
     if (!h || !actions) return ec::fail(EC_EINVAL, "null handle or actions");
-    hipLaunchKernelGGL(h->step, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_step, (hipStream_t)stream, h->d,
-                       actions, reward, terminated, counters, completion_time, next_obs, next_avail, pol);
+    hipLaunchKernelGGL(pol.n_steps > 1 ? h->step_multi : h->step, dim3((unsigned)h->blocks), dim3(h->threads),
+                       h->lds_step, (hipStream_t)stream, h->d, h->d_dev, actions, reward, terminated, counters,
+                       completion_time, next_obs, next_avail, pol);
     if (hop_hist) {
         const int64_t n = h->d.B * h->d.H;
         hipLaunchKernelGGL(k_copy_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -2332,7 +2447,7 @@ static int step_impl(ec_handle h, const int64_t* actions, float* reward, uint8_t
 int ec_step(ec_handle h, const int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
             float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail, void* stream) {
     return step_impl(h, actions, reward, terminated, counters, completion_time, hop_hist, next_obs, next_avail,
-                     StepPolicy{0, 0, nullptr}, stream);
+                     StepPolicy{0, 0, nullptr, 1, 0}, stream);
 }
 
 int ec_step_random_policy(ec_handle h, const int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
@@ -2341,7 +2456,20 @@ int ec_step_random_policy(ec_handle h, const int64_t* actions, float* reward, ui
     if (!next_actions) return ec::fail(EC_EINVAL, "ec_step_random_policy: null next_actions");
     if (!next_avail) return ec::fail(EC_EINVAL, "ec_step_random_policy needs the fused observation (next_avail)");
     return step_impl(h, actions, reward, terminated, counters, completion_time, hop_hist, next_obs, next_avail,
-                     StepPolicy{seed, counter, next_actions}, stream);
+                     StepPolicy{seed, counter, next_actions, 1, 0}, stream);
+}
+
+int ec_rollout_random_policy(ec_handle h, int32_t n_steps, int32_t keep_history, const int64_t* actions, float* reward,
+                             uint8_t* terminated, int32_t* counters, float* completion_time, int32_t* hop_hist,
+                             float* next_obs, int32_t* next_avail, uint64_t seed, uint64_t counter,
+                             int64_t* next_actions, void* stream) {
+    if (n_steps < 1) return ec::fail(EC_EINVAL, "ec_rollout_random_policy: n_steps = %d", n_steps);
+    if (!next_actions) return ec::fail(EC_EINVAL, "ec_rollout_random_policy: null next_actions");
+    if (!next_avail) return ec::fail(EC_EINVAL, "ec_rollout_random_policy needs the fused observation (next_avail)");
+    if (keep_history && next_actions == actions)
+        return ec::fail(EC_EINVAL, "ec_rollout_random_policy: with keep_history the drawn actions need their own [n_steps,B,N] array");
+    return step_impl(h, actions, reward, terminated, counters, completion_time, hop_hist, next_obs, next_avail,
+                     StepPolicy{seed, counter, next_actions, n_steps, keep_history ? 1 : 0}, stream);
 }
 
 int ec_random_policy(const int32_t* avail, int64_t rows, int32_t n_actions, uint64_t seed, uint64_t counter,

@@ -123,6 +123,50 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
             info["hop_hist"] = self.hop_hist
         return self.reward, self.terminated, info, nxt
 
+    def rollout_random_policy(self, actions, n_steps, seed, counter=0, history=None, want_hops=False):
+        """n_steps calls of step_random_policy in one launch (ec_rollout_random_policy), same results.
+        history=None: in place (self.reward, self.obs, ... and `actions` hold what the last step left).
+        history=dict: per-step slices are written to its tensors, any subset of reward [K,B] f32, terminated [K,B]
+        u8, counters [K,B,4] i32, completion_time [K,B] f32, obs [K,B,N,9] f32 plus the required avail [K,B,N,A]
+        i32 and actions [K,B,N] i64 (actions[t] is the action taken at step t+1).  Returns `history` or, in place,
+        (reward, terminated, info, actions)."""
+        if actions.dtype != th.int64 or not actions.is_contiguous() or actions.device != self.device:
+            raise ValueError("actions must be a contiguous int64 tensor on the env's device")
+        n_steps = int(n_steps)
+        hops = _ptr(self.hop_hist) if want_hops else None
+        if history is None:
+            _abi.check(self.lib.ec_rollout_random_policy(
+                self._h, n_steps, 0, _ptr(actions), _ptr(self.reward), _ptr(self.terminated), _ptr(self.counters),
+                _ptr(self.completion_time), hops, _ptr(self.obs), _ptr(self.avail), int(seed), int(counter),
+                _ptr(actions), self._stream()), "ec_rollout_random_policy")
+            self._obs_valid = True
+            info = {"counters": self.counters, "task_completion_time": self.completion_time}
+            if want_hops:
+                info["hop_hist"] = self.hop_hist
+            return self.reward, self.terminated, info, actions
+        B, N = self.n_envs, self.n_agents
+        shapes = {"reward": ((n_steps, B), th.float32), "terminated": ((n_steps, B), th.uint8),
+                  "counters": ((n_steps, B, 4), th.int32), "completion_time": ((n_steps, B), th.float32),
+                  "obs": ((n_steps, B, N, 9), th.float32), "avail": ((n_steps, B, N, N + 1), th.int32),
+                  "actions": ((n_steps, B, N), th.int64)}
+        ptr = {}
+        for key, (shape, dtype) in shapes.items():
+            t = history.get(key)
+            if t is None:
+                if key in ("avail", "actions"):
+                    raise ValueError("history needs '%s'" % key)
+                ptr[key] = None
+                continue
+            if tuple(t.shape) != shape or t.dtype != dtype or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("history['%s'] must be a contiguous %s tensor of shape %s on the env's device" % (key, dtype, shape))
+            ptr[key] = _ptr(t)
+        _abi.check(self.lib.ec_rollout_random_policy(
+            self._h, n_steps, 1, _ptr(actions), ptr["reward"], ptr["terminated"], ptr["counters"],
+            ptr["completion_time"], hops, ptr["obs"], ptr["avail"], int(seed), int(counter), ptr["actions"],
+            self._stream()), "ec_rollout_random_policy")
+        self._obs_valid = False  # self.obs / self.avail were not written: observe() again before reading them
+        return history
+
     def step(self, actions, want_hops=False, fuse_observe=True):
         """actions: int64 [B,N] device tensor.  Returns (reward[B] f32, terminated[B] u8, info) where info holds
         device tensors: the four counters of edge_computing_env.py:130-135 as columns of `counters`,

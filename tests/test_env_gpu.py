@@ -288,3 +288,54 @@ def test_fused_random_policy_equals_separate_launches(name, B):
     for e in envs:
         assert e.status() & ~32 == 0
         e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B,chunk", [("env10", 64, 7), ("env10", 33, 100), ("env40", 9, 13)])
+def test_rollout_random_policy_equals_per_step_launches(name, B, chunk):
+    """ec_rollout_random_policy (n steps in one launch) == n calls of ec_step_random_policy: every per-step output
+    (history mode) and what is left behind (in-place mode), over an episode boundary, with ragged chunking and a
+    batch that leaves the last block partly empty."""
+    th = _th()
+    g = load_golden(name)
+    args = args_from_golden(g)
+    N, T = args.edge_node_num, args.episode_limit
+    envs = [_make_env(args, B, 5) for _ in range(3)]   # 0: per-step launches, 1: history rollout, 2: in-place rollout
+    acts = [th.empty(B, N, dtype=th.int64, device=e.device) for e in envs]
+    dev = envs[0].device
+    for ep in range(2):
+        for e, a in zip(envs, acts):
+            e.reset()
+            e.observe()
+            e.random_actions(seed=11, counter=900 + ep, out=a)
+        t = 0
+        while t < T:
+            k = min(chunk, T - t)
+            ref = {key: [] for key in ("reward", "terminated", "counters", "completion_time", "obs", "avail", "actions")}
+            for _ in range(k):
+                r, term, info, nxt = envs[0].step_random_policy(acts[0], seed=11, counter=3)
+                for key, val in (("reward", r), ("terminated", term), ("counters", info["counters"]),
+                                 ("completion_time", info["task_completion_time"]), ("obs", envs[0].obs),
+                                 ("avail", envs[0].avail), ("actions", nxt)):
+                    ref[key].append(val.clone())
+            hist = {"reward": th.empty(k, B, device=dev), "terminated": th.empty(k, B, dtype=th.uint8, device=dev),
+                    "counters": th.empty(k, B, 4, dtype=th.int32, device=dev),
+                    "completion_time": th.empty(k, B, device=dev), "obs": th.empty(k, B, N, 9, device=dev),
+                    "avail": th.empty(k, B, N, N + 1, dtype=th.int32, device=dev),
+                    "actions": th.empty(k, B, N, dtype=th.int64, device=dev)}
+            envs[1].rollout_random_policy(acts[1], k, seed=11, counter=3, history=hist)
+            for key in ref:
+                assert th.equal(th.stack(ref[key]), hist[key]), (ep, t, key)
+            acts[1].copy_(hist["actions"][-1])
+            r2, term2, info2, _ = envs[2].rollout_random_policy(acts[2], k, seed=11, counter=3)
+            assert th.equal(r2, ref["reward"][-1]) and th.equal(term2, ref["terminated"][-1]), (ep, t, "in-place outputs")
+            assert th.equal(info2["counters"], ref["counters"][-1]), (ep, t, "in-place counters")
+            assert th.equal(envs[2].obs, ref["obs"][-1]) and th.equal(envs[2].avail, ref["avail"][-1]), (ep, t)
+            assert th.equal(acts[2], ref["actions"][-1]), (ep, t, "in-place actions")
+            t += k
+        assert bool(ref["terminated"][-1].all())
+    dumps = [e.debug_dump(B - 1) for e in envs]
+    assert np.array_equal(dumps[0], dumps[1]) and np.array_equal(dumps[0], dumps[2])
+    for e in envs:
+        assert e.status() & ~32 == 0
+        e.close()
