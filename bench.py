@@ -3,10 +3,15 @@
 
 Workload (BASELINE.json configs[1]): the batched edge_computing environment, 4096 envs x 10 agents per
 GPU, task_size_max=6000, uniform-random policy over the availability mask.  One "step" = one pass of
-the rollout hot path over the whole batch: ec_step (offload, 10 mini-slots of execute/receive, statistics,
-generate_task) with the next observation + availability mask and the random policy's draw for the next step
-fused into the same launch; every episode_limit steps the envs are reset as ParallelRunner does.  Inputs and all state
-are resident in HBM; nothing crosses PCIe inside the timed region.
+the rollout hot path over the whole batch: the env step (offload, 10 mini-slots of execute/receive, statistics,
+generate_task) with the next observation + availability mask and the random policy's draw for the next step;
+every episode_limit steps the envs are reset as ParallelRunner does.  Inputs and all state are resident in HBM;
+nothing crosses PCIe inside the timed region.
+
+--launch rollout (default): ec_rollout_random_policy, one launch per episode (the looping instantiation of k_step).
+--launch graph / eager:     ec_step_random_policy, one launch per step (replayed from a hipGraph per episode / eager);
+                            the N=1 line reports this path too, under "per_step_launch".
+Every step writes its reward, counters, termination flag, observation, mask and next actions in both.
 
     python bench.py --gpus 1 --steps 1000 --warmup 200
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -35,9 +40,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=200)
     p.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     p.add_argument("--nodes", type=int, default=10, help="edge_node_num")
-    p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    p.add_argument("--launch", choices=("rollout", "graph", "eager"), default="rollout")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
-    p.add_argument("--roofline-steps", type=int, default=200)
+    p.add_argument("--roofline-steps", type=int, default=400)
     p.add_argument("--geometry", default="", help="override the step kernel's launch geometry: epw,mw[,producers]")
     p.add_argument("--ppo-iters", type=int, default=3,
                    help="also time this many PPO iterations (rollout + update) at N=1 and report them beside the metric")
@@ -47,16 +52,17 @@ def parse():
 class Rollout:
     """The hot path of ParallelRunner.run (parallel_episode_runner.py:32-113) on device tensors."""
 
-    def __init__(self, env, use_graph):
+    def __init__(self, env, launch):
         import torch as th
         self.th = th
         self.env = env
+        self.launch = launch
         self.T = env.episode_limit
         self.actions = th.empty(env.n_envs, env.n_agents, dtype=th.int64, device=env.device)
         self.counter_dev = th.zeros(2, dtype=th.int64, device=env.device)
         self.graph = None
         self.steps_done = 0
-        if use_graph:
+        if launch == "graph":
             # warm the kernels on a side stream, then capture one whole episode
             s = th.cuda.Stream(device=env.device)
             s.wait_stream(th.cuda.current_stream(env.device))
@@ -70,12 +76,16 @@ class Rollout:
 
     def _episode(self, n):
         # the first actions of an episode come from the policy kernel; every step then draws the next step's actions
-        # from the mask it has just produced, in the same launch (ec_step_random_policy), in place
+        # from the mask it has just produced (in place): n launches of ec_step_random_policy, or one of
+        # ec_rollout_random_policy
         self.env.reset()
         self.env.observe()
         self.env.random_actions(seed=0, counter=0, out=self.actions, counter_dev=self.counter_dev)
-        for _ in range(n):
-            self.env.step_random_policy(self.actions, seed=0)
+        if self.launch == "rollout":
+            self.env.rollout_random_policy(self.actions, n, seed=0)
+        else:
+            for _ in range(n):
+                self.env.step_random_policy(self.actions, seed=0)
 
     def run(self, n_steps):
         """Run exactly n_steps env steps (whole episodes first, then a partial one)."""
@@ -97,12 +107,12 @@ def algorithmic_bytes_per_env_step(N, live, draws):
     return io + 2 * 16 * N + 2 * 40 * live + 16 * draws
 
 
-def recorded_traffic():
+def recorded_traffic(name="pmc_traffic_k_step.json"):
     """HBM bytes per k_step launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc runs of
     tools/prof_step.py for FETCH_SIZE and WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes; bench.py cannot
     run under the profiler itself).  None when no such record exists."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_k_step.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
     if not files:
         return None, None
     with open(files[-1]) as f:
@@ -111,10 +121,23 @@ def recorded_traffic():
 
 
 def measure_roofline(env, roll, n_steps):
-    """Average ec_step kernel duration from HIP events recorded on the launch stream around each launch (one pass with
-    no host synchronisation inside), then the measured L-bar (live tasks/env) and D-bar (MT19937 doubles/env-step) of
-    a second pass over the same number of steps."""
+    """Average kernel durations from HIP events recorded on the launch stream around each launch (passes with no host
+    synchronisation inside): the one-step k_step (ec_step_random_policy) and the looping k_step of
+    ec_rollout_random_policy (episode_limit steps per launch); then the measured L-bar (live tasks/env) and D-bar
+    (MT19937 doubles/env-step) of a further pass over the same number of steps."""
     import torch as th
+
+    def run_rollout(events):
+        for ep in range(max(1, n_steps // env.episode_limit)):
+            env.reset()
+            env.observe()
+            env.random_actions(seed=0, counter=0, out=roll.actions, counter_dev=roll.counter_dev)
+            a, b = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+            a.record()
+            env.rollout_random_policy(roll.actions, env.episode_limit, seed=0)
+            b.record()
+            events.append((a, b))
+        th.cuda.synchronize(env.device)
 
     def run(sample_live, events):
         env.reset()
@@ -149,7 +172,10 @@ def measure_roofline(env, roll, n_steps):
     cur1 = env.debug_rng_cursors().astype("float64").sum()
     draws = (cur1 - cur0) / 2.0 / (n_steps * env.n_envs)
     lbar = sum(live) / max(1, len(live))
-    return avg_ms, ms[len(ms) // 2], lbar, draws
+    pairs = []
+    run_rollout(pairs)
+    rms = sorted(a.elapsed_time(b) for a, b in pairs)
+    return avg_ms, ms[len(ms) // 2], sum(rms) / len(rms), rms[len(rms) // 2], lbar, draws
 
 
 def cpu_baseline(args_ns, tables, n_envs, budget_s):
@@ -238,7 +264,7 @@ def main():
     ns = make_args(["--task_size_max=6000", "--seed=100", "--edge_node_num=%d" % a.nodes])
     B, N = a.envs, a.nodes
     env = BatchedEdgeComputingEnv(ns, n_envs=B, env_id_base=rank * B, device=dev)
-    roll = Rollout(env, use_graph=not a.no_graph)
+    roll = Rollout(env, a.launch)
 
     def fence():
         th.cuda.synchronize(dev)
@@ -270,20 +296,35 @@ def main():
             "config": {"workload": "edge_computing env step, %d envs/GPU x %d agents, task_size_max=6000, "
                                    "uniform-random policy over the avail mask, reset every %d steps "
                                    "(BASELINE.json configs[1])" % (B, N, env.episode_limit),
-                       "envs_per_gpu": B, "agents": N, "launch": "eager" if a.no_graph else "hipGraph per episode",
+                       "envs_per_gpu": B, "agents": N,
+                       "launch": {"rollout": "ec_rollout_random_policy, one launch per episode",
+                                  "graph": "ec_step_random_policy per step, hipGraph per episode",
+                                  "eager": "ec_step_random_policy per step, eager"}[a.launch],
                        "geometry": env.info_geometry()},
         }
     if rank == 0 and world == 1:
-        avg_ms, med_ms, lbar, draws = measure_roofline(env, roll, a.roofline_steps)
+        avg_ms, med_ms, ravg_ms, rmed_ms, lbar, draws = measure_roofline(env, roll, a.roofline_steps)
         bytes_step = algorithmic_bytes_per_env_step(N, lbar, draws) * B
-        achieved = bytes_step / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = recorded_traffic() if (B == 4096 and N == 10) else (None, None)
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                           "kernel": "k_step",
-                           "kernel_avg_us": avg_ms * 1e3, "kernel_median_us": med_ms * 1e3,
-                           "algorithmic_bytes_per_launch": bytes_step, "live_tasks_per_env": lbar,
-                           "rng_doubles_per_env_step": draws}
+        T = env.episode_limit
+        std = B == 4096 and N == 10
+        one = {"bound": "hbm", "achieved": bytes_step / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "kernel": "k_step<.., one step>", "env_steps_per_launch": 1,
+               "kernel_avg_us": avg_ms * 1e3, "kernel_median_us": med_ms * 1e3,
+               "algorithmic_bytes_per_launch": bytes_step}
+        one["traffic"], one["traffic_source"] = recorded_traffic() if std else (None, None)
+        many = {"bound": "hbm", "achieved": bytes_step * T / (ravg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "kernel": "k_step<.., looping>", "env_steps_per_launch": T,
+                "kernel_avg_us": ravg_ms * 1e3, "kernel_median_us": rmed_ms * 1e3,
+                "algorithmic_bytes_per_launch": bytes_step * T}
+        many["traffic"], many["traffic_source"] = recorded_traffic("pmc_traffic_k_step_rollout.json") if std else (None, None)
+        for r in (one, many):
+            r["frac"] = r["achieved"] / HBM_PEAK_GBS
+            r["live_tasks_per_env"], r["rng_doubles_per_env_step"] = lbar, draws
+        # the dominant kernel of the timed region above; the other launch mode beside it
+        out["roofline"] = many if a.launch == "rollout" else one
+        other = one if a.launch == "rollout" else many
+        other["agent_steps_per_s_kernel_only"] = B * N * other["env_steps_per_launch"] / (other["kernel_avg_us"] * 1e-6)
+        out["per_step_launch" if a.launch == "rollout" else "rollout_launch"] = other
         if a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(ns, env.tables, B, a.cpu_seconds)
     env.close()
