@@ -982,11 +982,31 @@ __device__ __forceinline__ u64 policy_hash(u64 seed, u64 counter, u64 rows, u64 
 // EdgeComputingEnv.step (edge_computing_env.py:84-143) for the envs of this block.
 // KMAX >= k and DMAX >= max in-degree are compile-time so that the executing slots and the receiving-queue
 // scalars live in registers and the per-mini-slot work is branch-free except for events.
+// What a main lane of the looping kernel keeps in registers from one step to the next (its queues stay in LDS):
+// with it, the steps between the first and the last of a launch neither stage their state from global memory nor
+// write it back.
+template <int KMAX, int DMAX>
+struct StepCarry {
+    u32 c0, steps_before, has_new, n_off, ex_n, wq_h, wq_len, wq_min, exA_thr;
+    bool wq_dirty;
+    int deg;
+    int64_t action;  // drawn by the previous step's policy tail
+    double cap;
+    u32 lkA[DMAX];
+    u32 exw[KMAX], exh[KMAX];
+    double exT[KMAX];
+    Rec newt;
+    u32 buf_head, buf_len;
+};
+
+// first: the lane's state comes from global memory (else from `cr` and the LDS arrays as the previous step left
+// them); last: it is written back.  One-step launches are both.
 template <int KMAX, int DMAX>
 __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restrict__ actions, float* __restrict__ reward,
                                           uint8_t* __restrict__ terminated, int32_t* __restrict__ counters,
                                           float* __restrict__ completion_time, float* __restrict__ next_obs,
-                                          int32_t* __restrict__ next_avail, StepPolicy pol) {
+                                          int32_t* __restrict__ next_avail, StepPolicy pol, StepCarry<KMAX, DMAX>& cr,
+                                          const bool first, const bool last) {
     static_assert(RB_FAIL >= KMAX + DMAX, "failure window too small");
     static_assert(RB_FAIL * 4 >= 12 + 36, "observation scratch does not fit the failure window");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1028,7 +1048,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
     const bool producer_wave = has_producers ? (int)threadIdx.x >= d.nmain : true;  // wave-uniform
     const int tid = L.lidx;  // slot of this main lane in the per-lane LDS arrays
     double lut_lo[ACC_LDS / 64];  // block-shared low part of the tick LUT: loaded by the producer lanes with their
-    if (producer_wave) {          // first round of loads, stored to LDS before the first barrier
+    if (producer_wave && first) { // first round of loads, stored to LDS before the first barrier
         const int p0 = has_producers ? (int)threadIdx.x - d.nmain : (int)threadIdx.x;
         const int np = has_producers ? (int)blockDim.x - d.nmain : (int)blockDim.x;
 #pragma unroll
@@ -1076,7 +1096,39 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         lkA[s] = 0xffffffffu;
     }
     u32 steps_before = 0;
-    if (L.valid) {
+    if (L.valid && !first) {
+        // carried over: registers from `cr`, queues in LDS; only the head of the buffer ring is (re)loaded
+        c0 = cr.c0;
+        steps_before = cr.steps_before;
+        has_new = cr.has_new;
+        n_off = cr.n_off;
+        ex_n = cr.ex_n;
+        wq_h = cr.wq_h;
+        wq_len = cr.wq_len;
+        wq_min = cr.wq_min;
+        wq_dirty = cr.wq_dirty;
+        exA_thr = cr.exA_thr;
+        deg = cr.deg;
+        action = cr.action;
+        cap = cr.cap;
+        newt = cr.newt;
+        buf.head = cr.buf_head;
+        buf.len = cr.buf_len;
+        if (buf.len > 0) buf.head_rec = load_rec(d.buf + (size_t)buf.head * P + lane);
+#pragma unroll
+        for (int s = 0; s < DMAX; s++) lkA[s] = cr.lkA[s];
+#pragma unroll
+        for (int s = 0; s < KMAX; s++) {
+            exw[s] = cr.exw[s];
+            exh[s] = cr.exh[s];
+            exT[s] = cr.exT[s];
+        }
+        if (has_new && action >= 0 && action < N && action != node) {
+            slot = d.slot_of[node * N + (int)action];
+            rate = d.rate[node * N + (int)action];
+        }
+    }
+    if (L.valid && first) {
         c0 = d.tick[L.env];
         steps_before = d.total_steps[L.env];
         has_new = d.has_new[lane];
@@ -1251,7 +1303,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         S.rc[RC_TAHEAD * NT + ri] = pt.ahead;
         S.rc[RC_DONE * NT + ri] = 0;
     }
-    if (producer_wave) {
+    if (producer_wave && first) {
         const int p0 = has_producers ? (int)threadIdx.x - d.nmain : (int)threadIdx.x;
         const int np = has_producers ? (int)blockDim.x - d.nmain : (int)blockDim.x;
 #pragma unroll
@@ -1696,44 +1748,77 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                     S.rc[RC_TAHEAD * NT + tid] + S.rc[RC_TDELTA * NT + tid], S.tu[0 * NT + tid], S.tu[1 * NT + tid],
                     S.tu[2 * NT + tid], S.tu[3 * NT + tid]);
         generate_task(d, lane, d.bin_qn[node], d.bin_px2[node], d.bin_flip[node], trng, buf, n_off, has_new, nnew);
-        d.has_new[lane] = has_new;
-        if (has_new) store_rec(d.newt + lane, nnew);
-        d.n_off[lane] = n_off;
-        d.buf_head[lane] = buf.head;
-        d.buf_len[lane] = buf.len;
-        d.wq_len[lane] = wq_len;
         for (u32 j = 0; j < wq_len; j++) {
             const u32 pos = (wq_h + j) & wmask;
             const double et = S.wqe[pos * NT + tid];
             wait_sum = dadd(wait_sum, et);  // get_waiting_time, edge_node.py:99-104
-            if (wq_dirty) {
+            if (last && wq_dirty) {
                 d.wqm[(size_t)j * P + lane] = S.wqm[pos * NT + tid];
                 d.wqe[(size_t)j * P + lane] = et;
             }
         }
-        d.ex_n[lane] = ex_n;
+        if (last) {
+            d.has_new[lane] = has_new;
+            if (has_new) store_rec(d.newt + lane, nnew);
+            d.n_off[lane] = n_off;
+            d.buf_head[lane] = buf.head;
+            d.buf_len[lane] = buf.len;
+            d.wq_len[lane] = wq_len;
+            d.ex_n[lane] = ex_n;
 #pragma unroll
-        for (int s = 0; s < KMAX; s++) {
-            if ((u32)s < ex_n) {
-                d.exA[(size_t)s * P + lane] = (u64)exw[s] | ((u64)exh[s] << 32);
-                d.exB[(size_t)s * P + lane] = exT[s];
-                d.exC[(size_t)s * P + lane] = S.exC[s * NT + tid];
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < DMAX; s++) {
-            if (s < deg) {
-                const size_t so = (size_t)s * P + lane;
-                const u32 qh = S.rqhead[s * NT + tid];
-                d.rq_len[so] = rql[s];
-                d.rq_head[so] = qh;
-                d.rq_arrive[so] = rqa[s];
-                d.rq_hstart[so] = S.rqhs[s * NT + tid];
-                if (rql[s] > 0 && S.rqdirty[s * NT + tid]) {
-                    uint4* q = reinterpret_cast<uint4*>(d.rq + ((size_t)s * d.capR + qh) * P + lane);
-                    q[0] = S.rqrec[(s * 2 + 0) * NT + tid];
-                    q[1] = S.rqrec[(s * 2 + 1) * NT + tid];
+            for (int s = 0; s < KMAX; s++) {
+                if ((u32)s < ex_n) {
+                    d.exA[(size_t)s * P + lane] = (u64)exw[s] | ((u64)exh[s] << 32);
+                    d.exB[(size_t)s * P + lane] = exT[s];
+                    d.exC[(size_t)s * P + lane] = S.exC[s * NT + tid];
                 }
+            }
+#pragma unroll
+            for (int s = 0; s < DMAX; s++) {
+                if (s < deg) {
+                    const size_t so = (size_t)s * P + lane;
+                    const u32 qh = S.rqhead[s * NT + tid];
+                    d.rq_len[so] = rql[s];
+                    d.rq_head[so] = qh;
+                    d.rq_arrive[so] = rqa[s];
+                    d.rq_hstart[so] = S.rqhs[s * NT + tid];
+                    if (rql[s] > 0 && S.rqdirty[s * NT + tid]) {
+                        uint4* q = reinterpret_cast<uint4*>(d.rq + ((size_t)s * d.capR + qh) * P + lane);
+                        q[0] = S.rqrec[(s * 2 + 0) * NT + tid];
+                        q[1] = S.rqrec[(s * 2 + 1) * NT + tid];
+                    }
+                }
+            }
+        } else {
+            // the next step of this launch continues from registers and LDS
+            cr.c0 = c0 + (u32)d.S;
+            cr.steps_before = steps_before + 1;
+            cr.has_new = has_new;
+            cr.n_off = n_off;
+            cr.ex_n = ex_n;
+            cr.wq_h = wq_h;
+            cr.wq_len = wq_len;
+            cr.wq_min = wq_min;
+            cr.wq_dirty = wq_dirty;
+            cr.exA_thr = exA_thr;
+            cr.deg = deg;
+            cr.cap = cap;
+            cr.newt = nnew;
+            cr.buf_head = buf.head;
+            cr.buf_len = buf.len;
+#pragma unroll
+            for (int s = 0; s < DMAX; s++) {
+                cr.lkA[s] = lkA[s];
+                if (s < deg) {  // the pushes of the next step's phase A look at these
+                    S.rqlen[s * NT + tid] = rql[s];
+                    S.rqarr[s * NT + tid] = rqa[s];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < KMAX; s++) {
+                cr.exw[s] = exw[s];
+                cr.exh[s] = exh[s];
+                cr.exT[s] = exT[s];
             }
         }
         u32 pos, ahead, used;
@@ -1804,10 +1889,17 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                     }
                 }
                 pol.next_actions[lane] = act;
+                cr.action = act;
             }
         }
     }
     EC_STAMP(8);
+#ifdef EC_STAMPS
+    if (d.stamps && (threadIdx.x == 0 || (int)threadIdx.x == d.nmain)) {  // where the two waves run: HW_ID | XCC_ID << 32
+        const u64 hw = (u64)__builtin_amdgcn_s_getreg(63492) | ((u64)__builtin_amdgcn_s_getreg(63508) << 32);
+        d.stamps[(size_t)blockIdx.x * 16 + (threadIdx.x == 0 ? 14 : 15)] = hw;
+    }
+#endif
 }
 
 // One env step per launch (ec_step, ec_step_random_policy), or -- MULTI -- pol0.n_steps of them in one launch
@@ -1818,12 +1910,13 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
 // a pointer the compiler cannot see through: held in registers across the whole body instead, its ~150 words
 // double the spills of the step code.
 template <int KMAX, int DMAX, bool MULTI>
-__global__ void __launch_bounds__(256) k_step(EcDev d_arg, const EcDev* d_mem, const int64_t* actions0, float* reward0,
+__global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem, const int64_t* actions0, float* reward0,
                                               uint8_t* terminated0, int32_t* counters0, float* completion_time0,
                                               float* next_obs0, int32_t* next_avail0, StepPolicy pol0) {
+    StepCarry<KMAX, DMAX> cr;
     if (!MULTI) {
         step_body<KMAX, DMAX>(d_arg, actions0, reward0, terminated0, counters0, completion_time0, next_obs0, next_avail0,
-                              pol0);
+                              pol0, cr, true, true);
         return;
     }
     for (int it = 0; it < pol0.n_steps; it++) {
@@ -1846,8 +1939,9 @@ __global__ void __launch_bounds__(256) k_step(EcDev d_arg, const EcDev* d_mem, c
                               reward0 ? reward0 + hs * d.B : nullptr, terminated0 ? terminated0 + hs * d.B : nullptr,
                               counters0 ? counters0 + hs * d.B * 4 : nullptr,
                               completion_time0 ? completion_time0 + hs * d.B : nullptr,
-                              next_obs0 ? next_obs0 + hs * d.P * 9 : nullptr, next_avail0 + hs * d.P * d.A, pol);
-        __syncthreads();  // LDS is restaged, and this block's global writes are re-read
+                              next_obs0 ? next_obs0 + hs * d.P * 9 : nullptr, next_avail0 + hs * d.P * d.A, pol, cr,
+                              it == 0, it + 1 == pol0.n_steps);
+        __syncthreads();  // the step is complete in LDS and (RNG cursors, MT words) in this block's global memory
     }
 }
 

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Diagnostic (EC_STAMPS build, MARL_AMD_LIB): per-block duration of the last step of a looping launch against where
+the block's main and producer waves run (XCC, SE, CU, SIMD from HW_ID)."""
+import ctypes as C
+import collections
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch as th  # noqa: E402
+
+from marl_amd import _abi  # noqa: E402
+from marl_amd.envs.edge_computing.multihop.edge_computing_env import BatchedEdgeComputingEnv  # noqa: E402
+from tests.util import make_args  # noqa: E402
+
+B = 4096
+ns = make_args(["--task_size_max=6000"])
+env = BatchedEdgeComputingEnv(ns, n_envs=B)
+L = _abi.lib()
+L.ec_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+act = th.empty(B, 10, dtype=th.int64, device=env.device)
+env.reset()
+env.observe()
+env.random_actions(seed=0, counter=0, out=act)
+env.rollout_random_policy(act, 60, seed=0)
+nb = B // env.info_geometry()["envs_per_block"] + 1
+buf = np.zeros((nb + 8) * 16, dtype=np.uint64)
+n = C.c_int64()
+L.ec_debug_stamps(env._h, buf.ctypes.data_as(C.c_void_p), C.byref(n))
+s = buf[: n.value * 16].reshape(n.value, 16)
+end = s[:, 8].astype(np.int64)
+dur = (s[:, 8].astype(np.int64) - s[:, 0].astype(np.int64)) / 100.0
+
+
+def place(w):
+    hw, xcc = int(w) & 0xffffffff, (int(w) >> 32) & 0xf
+    return xcc, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15, (hw >> 4) & 3  # xcc, se, sh, cu, simd
+
+
+cus = collections.defaultdict(list)
+for b in range(n.value):
+    m, p = place(s[b, 14]), place(s[b, 15])
+    cus[m[:4]].append((m[4], p[4], end[b], dur[b]))
+print("blocks", n.value, "CUs used", len(cus), "blocks/CU", collections.Counter(len(v) for v in cus.values()))
+# finishing time of the launch's last step relative to the earliest block, by whether the main wave shares its SIMD
+t0 = end.min()
+shared, alone = [], []
+for cu, v in cus.items():
+    simds = collections.Counter(x[0] for x in v)
+    for msimd, psimd, e, du in v:
+        (shared if simds[msimd] > 1 else alone).append(((e - t0) / 100.0, du))
+for name, arr in (("main wave shares its SIMD with another main", shared), ("main wave alone on its SIMD", alone)):
+    if arr:
+        a = np.array(arr)
+        print("%-46s n=%4d  end of step 60 after the first block: mean %6.1f us  max %6.1f us   last-step duration mean %5.1f us"
+              % (name, len(a), a[:, 0].mean(), a[:, 0].max(), a[:, 1].mean()))
+print("main SIMD histogram", collections.Counter(place(s[b, 14])[4] for b in range(n.value)))
+print("producer SIMD histogram", collections.Counter(place(s[b, 15])[4] for b in range(n.value)))

@@ -24,10 +24,16 @@ env.observe()
 names = ["entry->staged", "offload", "fail window", "tick0", "tick1", "ticks 2..9", "reduce", "generate+writeback",
          "(unused)", "observe", "producer: window+doubles (from entry)", "producer: regeneration (from offload end)"]
 acc = []
-for t in range(160):
-    env.random_actions(seed=0, counter=t, out=act)
-    env.step(act)
-    if t >= 60 and t % 10 == 0:
+ROLL = int(os.environ.get("STAMPS_ROLLOUT", "0"))  # >1: steps per launch through the looping kernel (last one is stamped)
+if ROLL:
+    env.random_actions(seed=0, counter=0, out=act)
+for t in range(160 if not ROLL else 160 // ROLL):
+    if ROLL:
+        env.rollout_random_policy(act, ROLL, seed=0)
+    else:
+        env.random_actions(seed=0, counter=t, out=act)
+        env.step(act)
+    if (t >= 60 and t % 10 == 0) if not ROLL else (t * ROLL >= 60):
         nb = env.info_geometry()["B"] // env.info_geometry()["envs_per_block"] + 1
         buf = np.zeros((nb + 8) * 16, dtype=np.uint64)
         n = C.c_int64()
