@@ -166,7 +166,7 @@ int ec_debug_rng_cursors(ec_handle h, uint64_t* cursors_host);
 int ec_debug_live_tasks(ec_handle h, int64_t* total_host);
 /* geometry chosen by ec_create: {B, N, k, D(max in-degree), cap_buffer, cap_recv, cap_wait, max_ticks,
  * threads_per_block, envs_per_block, state_bytes_lo, state_bytes_hi, lds_bytes_per_block, envs_per_wave,
- * main_waves, rng_producer_waves}; the first n (<= 16) are written */
+ * main_waves, rng_producer_waves, rollout_kernel_resident}; the first n (<= 17) are written */
 int ec_info(ec_handle h, int64_t* info_host, int32_t n);
 
 /* --- GAE: replaces utils/advantage_utils.py:4-9 ------------------------------------------------ */

@@ -1262,7 +1262,9 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
     if (R.valid) {
         const int ri = R.lidx;
         const size_t tl = (size_t)R.lane, fl = (size_t)P + (size_t)R.lane;
-        const u32 tpos = d.rng_pos[tl], tah = d.rng_ahead[tl], fpos = d.rng_pos[fl], fah = d.rng_ahead[fl];
+        // cursors: from global memory, or -- a carried step -- from where the consumer left them in LDS
+        const u32 tpos = first ? d.rng_pos[tl] : S.rc[RC_TPOS * NT + ri], tah = first ? d.rng_ahead[tl] : S.rc[RC_TAHEAD * NT + ri];
+        const u32 fpos = first ? d.rng_pos[fl] : S.rc[RC_FPOS * NT + ri], fah = first ? d.rng_ahead[fl] : S.rc[RC_FAHEAD * NT + ri];
         RngTask pt;
         RngFail pf;
         if (tah >= (u32)AHEAD_TASK && fah >= (u32)AHEAD_FAIL) {
@@ -1700,6 +1702,17 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
 
     EC_STAMP(4);
     // ---------------------------------------------------------------- phase C: per-env statistics, edge_computing_env.py:108-123
+    // loads that phase D needs, issued before the barrier so that their latency hides behind it
+    double bin_qn = 0.0, bin_px2 = 0.0;
+    u32 bin_flip = 0;
+    u64 cnt_t = 0, cnt_f = 0;
+    if (L.valid) {
+        bin_qn = d.bin_qn[node];
+        bin_px2 = d.bin_px2[node];
+        bin_flip = d.bin_flip[node];
+        cnt_t = d.rng_cnt[lane];
+        cnt_f = d.rng_cnt[P + lane];
+    }
     if (L.valid) {
         S.rew[tid] = rew;
         S.ct[tid] = ct;
@@ -1747,7 +1760,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         trng.attach(d.mt + (size_t)lane * MT_STRIDE, S.rc[RC_TPOS * NT + tid],
                     S.rc[RC_TAHEAD * NT + tid] + S.rc[RC_TDELTA * NT + tid], S.tu[0 * NT + tid], S.tu[1 * NT + tid],
                     S.tu[2 * NT + tid], S.tu[3 * NT + tid]);
-        generate_task(d, lane, d.bin_qn[node], d.bin_px2[node], d.bin_flip[node], trng, buf, n_off, has_new, nnew);
+        generate_task(d, lane, bin_qn, bin_px2, bin_flip, trng, buf, n_off, has_new, nnew);
         for (u32 j = 0; j < wq_len; j++) {
             const u32 pos = (wq_h + j) & wmask;
             const double et = S.wqe[pos * NT + tid];
@@ -1823,13 +1836,23 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         }
         u32 pos, ahead, used;
         trng.close(pos, ahead, used);
-        d.rng_pos[lane] = pos;
-        d.rng_ahead[lane] = ahead;
-        d.rng_cnt[lane] += 2ull * used;
+        if (last) {
+            d.rng_pos[lane] = pos;
+            d.rng_ahead[lane] = ahead;
+        } else {  // the producer lane of the next step reads them here (after the step's closing barrier)
+            S.rc[RC_TPOS * NT + tid] = pos;
+            S.rc[RC_TAHEAD * NT + tid] = ahead;
+        }
+        d.rng_cnt[lane] = cnt_t + 2ull * used;
         frng.close(pos, ahead, used);
-        d.rng_pos[P + lane] = pos;
-        d.rng_ahead[P + lane] = ahead;
-        d.rng_cnt[P + lane] += 2ull * used;
+        if (last) {
+            d.rng_pos[P + lane] = pos;
+            d.rng_ahead[P + lane] = ahead;
+        } else {
+            S.rc[RC_FPOS * NT + tid] = pos;
+            S.rc[RC_FAHEAD * NT + tid] = ahead;
+        }
+        d.rng_cnt[P + lane] = cnt_f + 2ull * used;
         if (ovf | lut.ovf) flag(d, EC_ST_TICK_OVERFLOW);
     }
     EC_STAMP(6);
@@ -2157,6 +2180,7 @@ struct ec_env {
     step_fn step;        // one env step per launch
     step_fn step_multi;  // the same kernel looping over steps (ec_rollout_random_policy)
     EcDev* d_dev;        // device copy of `d` for the looping kernel
+    bool multi_resident; // every block of the looping kernel fits on the device at once
     int kmax, dmax;
     std::vector<void*> allocs;
     size_t state_bytes;
@@ -2448,6 +2472,12 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     EC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
     EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->step_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)h->lds_step));
+    {   // the looping kernel is correct at any residency (blocks are independent), but a second round doubles its time
+        int per_cu = 0;
+        EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(h->step_multi),
+                                                            h->threads, h->lds_step));
+        h->multi_resident = h->blocks <= (int64_t)per_cu * prop.multiProcessorCount;
+    }
 #ifdef EC_STAMPS
     EC_TRY(dev_alloc(h, &d.stamps, (size_t)h->blocks * 16, true));
 #endif
@@ -2642,11 +2672,11 @@ int ec_debug_live_tasks(ec_handle h, int64_t* total_host) {
 
 int ec_info(ec_handle h, int64_t* info_host, int32_t n) {
     if (!h || !info_host) return ec::fail(EC_EINVAL, "null argument");
-    const int64_t v[16] = {h->d.B, h->d.N, h->d.k, h->d.D, h->d.capB, h->d.capR, h->d.capW, h->d.maxTicks,
+    const int64_t v[17] = {h->d.B, h->d.N, h->d.k, h->d.D, h->d.capB, h->d.capR, h->d.capW, h->d.maxTicks,
                            h->threads, h->envs_per_block, (int64_t)(h->state_bytes & 0xffffffffull),
                            (int64_t)(h->state_bytes >> 32), (int64_t)h->lds_step,
-                           h->d.epw, h->d.nmain / 64, (h->threads - h->d.nmain) / 64};
-    for (int i = 0; i < n && i < 16; i++) info_host[i] = v[i];
+                           h->d.epw, h->d.nmain / 64, (h->threads - h->d.nmain) / 64, h->multi_resident ? 1 : 0};
+    for (int i = 0; i < n && i < 17; i++) info_host[i] = v[i];
     return EC_OK;
 }
 

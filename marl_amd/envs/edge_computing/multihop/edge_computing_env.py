@@ -225,14 +225,15 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
         return st
 
     def info_geometry(self):
-        v = (C.c_int64 * 16)()
-        _abi.check(self.lib.ec_info(self._h, v, 16), "ec_info")
+        v = (C.c_int64 * 17)()
+        _abi.check(self.lib.ec_info(self._h, v, 17), "ec_info")
         keys = ("B", "N", "k", "D", "cap_buffer", "cap_recv", "cap_wait", "max_ticks", "threads_per_block",
                 "envs_per_block")
         out = {k: int(v[i]) for i, k in enumerate(keys)}
         out["state_bytes"] = int(v[10]) | (int(v[11]) << 32)
         out["lds_bytes_per_block"] = int(v[12])
         out["envs_per_wave"], out["main_waves"], out["rng_producer_waves"] = int(v[13]), int(v[14]), int(v[15])
+        out["rollout_kernel_resident"] = bool(v[16])
         return out
 
     def debug_dump(self, env, max_rows=8192):

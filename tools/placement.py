@@ -58,3 +58,31 @@ for name, arr in (("main wave shares its SIMD with another main", shared), ("mai
               % (name, len(a), a[:, 0].mean(), a[:, 0].max(), a[:, 1].mean()))
 print("main SIMD histogram", collections.Counter(place(s[b, 14])[4] for b in range(n.value)))
 print("producer SIMD histogram", collections.Counter(place(s[b, 15])[4] for b in range(n.value)))
+# per XCC, and against the block's load (tasks alive in its envs at the end)
+byx = collections.defaultdict(list)
+for b in range(n.value):
+    byx[place(s[b, 14])[0]].append((end[b] - t0) / 100.0)
+print("end of last step after the first block, by XCC:", {k: round(float(np.mean(v)), 1) for k, v in sorted(byx.items())})
+epb = env.info_geometry()["envs_per_block"]
+th.cuda.synchronize()
+import ctypes
+P = B * 10
+def dl(name):
+    return None
+live = (env.debug_dump_counts() if hasattr(env, "debug_dump_counts") else None)
+if live is None:
+    # tasks per env from the public dump (slow path: sample 256 envs)
+    idx = np.linspace(0, B - 1, 256).astype(int)
+    load = np.array([len(env.debug_dump(int(e))) for e in idx])
+    blk = idx // epb
+    e_rel = (end[blk] - t0) / 100.0
+    print("corr(block finishing time, tasks alive in a sampled env of the block) = %.2f" % np.corrcoef(e_rel, load)[0, 1])
+cu_mean = {cu: float(np.mean([(x[2] - t0) / 100.0 for x in v])) for cu, v in cus.items()}
+within = float(np.mean([np.std([(x[2] - t0) / 100.0 for x in v]) for v in cus.values()]))
+vals = np.array(list(cu_mean.values()))
+print("per-CU mean finishing time: std across CUs %.1f us, mean std within a CU %.1f us; slowest CUs:" % (vals.std(), within),
+      sorted(((round(v, 1), cu) for cu, v in cu_mean.items()), reverse=True)[:6])
+bycu = collections.defaultdict(list)
+for cu, v in cu_mean.items():
+    bycu[cu[3]].append(v)
+print("by cu_id within the SE/SH:", {k: round(float(np.mean(v)), 1) for k, v in sorted(bycu.items())})
