@@ -339,3 +339,39 @@ def test_rollout_random_policy_equals_per_step_launches(name, B, chunk):
     for e in envs:
         assert e.status() & ~32 == 0
         e.close()
+
+
+@pytest.mark.parametrize("epw,mw,producers", [(1, 1, 1), (2, 2, 1), (2, 3, 1), (3, 1, 0), (6, 1, 1), (1, 4, 0)])
+def test_lockstep_launch_geometries(oracle_lib, monkeypatch, epw, mw, producers):
+    """Every launch geometry ec_create can pick (envs per main wave x main waves, with or without RNG producer waves)
+    gives the oracle's trajectories; so does the looping kernel on top of it."""
+    monkeypatch.setenv("MARL_AMD_EC_EPW", str(epw))
+    monkeypatch.setenv("MARL_AMD_EC_MW", str(mw))
+    monkeypatch.setenv("MARL_AMD_EC_PRODUCERS", str(producers))
+    g = load_golden("env10")
+    args = args_from_golden(g)
+    _lockstep(args, 37, 11, 130, "random_valid", oracle_lib, dump_envs=(0, 36))
+    th = _th()
+    a_env, b_env = _make_env(args, 37, 2), _make_env(args, 37, 2)
+    geo = a_env.info_geometry()
+    assert (geo["envs_per_wave"], geo["main_waves"], geo["rng_producer_waves"] > 0) == (epw, mw, bool(producers))
+    acts = [th.empty(37, args.edge_node_num, dtype=th.int64, device=a_env.device) for _ in range(2)]
+    for e, a in zip((a_env, b_env), acts):
+        e.reset()
+        e.observe()
+        e.random_actions(seed=3, counter=1, out=a)
+    for _ in range(23):
+        a_env.step_random_policy(acts[0], seed=3, counter=9)
+    b_env.rollout_random_policy(acts[1], 23, seed=3, counter=9)
+    assert th.equal(acts[0], acts[1]) and th.equal(a_env.obs, b_env.obs) and th.equal(a_env.reward, b_env.reward)
+    assert np.array_equal(a_env.debug_dump(36), b_env.debug_dump(36))
+    assert np.array_equal(a_env.debug_rng_cursors(), b_env.debug_rng_cursors())
+    a_env.close()
+    b_env.close()
+
+
+def test_lockstep_env_wider_than_a_wave(oracle_lib):
+    """80 nodes: one env spans two main waves (contiguous lane mapping, two producer waves)."""
+    from tests.util import make_args
+    args = make_args(["--edge_node_num=80", "--task_size_max=6000", "--seed=3"])
+    _lockstep(args, 5, 0, 60, "random_valid", oracle_lib, dump_envs=(0, 4), check_every=2)
