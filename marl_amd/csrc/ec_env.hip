@@ -1942,6 +1942,12 @@ __global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem
                               pol0, cr, true, true);
         return;
     }
+#ifdef EC_STAMPS
+    if (threadIdx.x == 0 && d_arg.stamps) d_arg.stamps[(size_t)blockIdx.x * 16 + 13] = wall_clock64();  // launch entry
+#endif
+#ifdef EC_STAMPS
+    u64 dbg_prev = wall_clock64(), dbg_gap = 0, dbg_body = 0;
+#endif
     for (int it = 0; it < pol0.n_steps; it++) {
         size_t opaque = 0;  // an offset the compiler cannot see through: *dp is loaded anew in every iteration
         asm volatile("" : "+s"(opaque));
@@ -1958,14 +1964,28 @@ __global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem
         const int64_t hs = pol0.keep ? (int64_t)it : 0;  // history slot of this iteration's outputs
         StepPolicy pol = pol0;
         pol.next_actions += hs * d.P;
+#ifdef EC_STAMPS
+        const u64 dbg_t0 = wall_clock64();
+        dbg_gap += dbg_t0 - dbg_prev;
+#endif
         step_body<KMAX, DMAX>(d, it == 0 ? actions0 : pol0.next_actions + (pol0.keep ? (int64_t)(it - 1) * d.P : 0),
                               reward0 ? reward0 + hs * d.B : nullptr, terminated0 ? terminated0 + hs * d.B : nullptr,
                               counters0 ? counters0 + hs * d.B * 4 : nullptr,
                               completion_time0 ? completion_time0 + hs * d.B : nullptr,
                               next_obs0 ? next_obs0 + hs * d.P * 9 : nullptr, next_avail0 + hs * d.P * d.A, pol, cr,
                               it == 0, it + 1 == pol0.n_steps);
+#ifdef EC_STAMPS
+        dbg_prev = wall_clock64();
+        dbg_body += dbg_prev - dbg_t0;
+#endif
         __syncthreads();  // the step is complete in LDS and (RNG cursors, MT words) in this block's global memory
     }
+#ifdef EC_STAMPS
+    if (threadIdx.x == 0 && d_arg.stamps) {  // per block: time between step bodies (barrier + geometry reload) and inside them
+        d_arg.stamps[(size_t)blockIdx.x * 16 + 9] = dbg_gap;
+        d_arg.stamps[(size_t)blockIdx.x * 16 + 10] = dbg_body;
+    }
+#endif
 }
 
 typedef void (*step_fn)(EcDev, const EcDev*, const int64_t*, float*, uint8_t*, int32_t*, float*, float*, int32_t*, StepPolicy);

@@ -86,3 +86,40 @@ bycu = collections.defaultdict(list)
 for cu, v in cu_mean.items():
     bycu[cu[3]].append(v)
 print("by cu_id within the SE/SH:", {k: round(float(np.mean(v)), 1) for k, v in sorted(bycu.items())})
+grp = collections.defaultdict(list)
+for b in range(n.value):
+    m, p = place(s[b, 14]), place(s[b, 15])
+    grp[("main simd", m[4])].append((end[b] - t0) / 100.0)
+    grp[("prod simd", p[4])].append((end[b] - t0) / 100.0)
+    grp[("main wave slot", int(s[b, 14]) & 15)].append((end[b] - t0) / 100.0)
+    grp[("main-prod simd distance", (p[4] - m[4]) % 4)].append((end[b] - t0) / 100.0)
+for k in sorted(grp):
+    print(k, "n=%d mean %.1f" % (len(grp[k]), np.mean(grp[k])))
+# does a block's rank within its CU (by block index) matter?
+rank = collections.defaultdict(list)
+for cu, v in cus.items():
+    order = np.argsort([x[2] for x in v])
+blk_by_cu = collections.defaultdict(list)
+for b in range(n.value):
+    blk_by_cu[place(s[b, 14])[:4]].append(b)
+for cu, bl in blk_by_cu.items():
+    for r, b in enumerate(sorted(bl)):
+        rank[r].append((end[b] - t0) / 100.0)
+print("by order of block index within the CU:", {r: round(float(np.mean(v)), 1) for r, v in sorted(rank.items())})
+rk = collections.defaultdict(list)
+for cu, bl in blk_by_cu.items():
+    for r, b in enumerate(sorted(bl)):
+        rk[r].append(dur[b])
+print("last-step duration by order of block index within the CU:", {r: round(float(np.mean(v)), 2) for r, v in sorted(rk.items())})
+entry = s[:, 13].astype(np.int64)
+print("kernel entry of the block after the first block to enter: mean %.1f us, max %.1f us; by order of block index within the CU:"
+      % ((entry - entry.min()).mean() / 100.0, (entry - entry.min()).max() / 100.0),
+      {r: round(float(np.mean([(entry[b] - entry.min()) / 100.0 for b in bl_r])), 1)
+       for r, bl_r in sorted({r: [sorted(bl)[r] for bl in blk_by_cu.values() if len(bl) > r] for r in range(4)}.items())})
+gap, body = s[:, 9].astype(np.int64) / 100.0, s[:, 10].astype(np.int64) / 100.0
+for name, arr in (("between step bodies (end barrier + geometry reload)", gap), ("inside step bodies", body)):
+    print("%s, us per step by order of block index within the CU:" % name,
+          {r: round(float(np.mean([arr[sorted(bl)[r]] for bl in blk_by_cu.values() if len(bl) > r])) / 60.0, 2) for r in range(4)})
+for cu in list(blk_by_cu)[:4]:
+    print("CU", cu, [(r, "main simd %d slot %d" % (place(s[b, 14])[4], int(s[b, 14]) & 15), "prod simd %d slot %d" % (place(s[b, 15])[4], int(s[b, 15]) & 15),
+                     round(body[b] / 60.0, 1)) for r, b in enumerate(sorted(blk_by_cu[cu]))])

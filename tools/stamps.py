@@ -43,12 +43,15 @@ for t in range(160 if not ROLL else 160 // ROLL):
                         s[:, 4] - s[:, 10], s[:, 5] - s[:, 4], s[:, 6] - s[:, 5], s[:, 7] - s[:, 6], s[:, 8] - s[:, 7]], 1)
         seg = np.concatenate([seg, np.stack([s[:, 11] - s[:, 0], s[:, 12] - s[:, 2]], 1)], 1)
         restages = int((s[:, 13] > 0).sum()), int(s[:, 13].sum())
+        q = len(s) // 4
+        quart = [float((s[i * q:(i + 1) * q, 8] - s[i * q:(i + 1) * q, 0]).mean()) / 100.0 for i in range(4)]
         span = (s[:, 8].max() - s[:, 0].min())
         acc.append((seg.mean(0), seg.max(0), span, (s[:, 8] - s[:, 0]).mean(), s[:, 0].max() - s[:, 0].min()))
 m = np.mean([a[0] for a in acc], 0) / 100.0  # wall_clock64 ticks at 100 MHz -> us
 mx = np.mean([a[1] for a in acc], 0) / 100.0
 print("epb", env.info_geometry()["envs_per_block"], "blocks span %.1f us, mean block %.1f us, start skew %.1f us" % (
     np.mean([a[2] for a in acc]) / 100.0, np.mean([a[3] for a in acc]) / 100.0, np.mean([a[4] for a in acc]) / 100.0))
+print("mean block duration by quarter of the block index range: %s us" % " ".join("%.1f" % x for x in quart))
 print("window restages, cumulative over the %d steps so far: %d blocks with any, %d lane-restages" % ((t + 1,) + restages))
 for nm, a, b in zip(names, m, mx):
     print("  %-42s mean %6.2f us   max-block %6.2f us" % (nm, a, b))
