@@ -98,7 +98,7 @@ struct FastDiv {
     u32 d, m;
 };
 
-struct EcDev {
+struct alignas(16) EcDev {
     // geometry
     int N, A, k, D, S, T, H;
     int capB, capR, capW, maxTicks;
@@ -1954,11 +1954,17 @@ __global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem
         const EcDev* dp = d_mem + opaque;
         EcDev d;
         {   // uniform words: into SGPRs (a plain copy would sit in ~150 VGPRs)
-            static_assert(sizeof(EcDev) % 4 == 0, "EcDev is copied word by word");
-            const u32* src = reinterpret_cast<const u32*>(dp);
+            static_assert(sizeof(EcDev) % 16 == 0, "EcDev is copied in 16-byte pieces");
+            const u32x4* src = reinterpret_cast<const u32x4*>(dp);
             u32* dst = reinterpret_cast<u32*>(&d);
 #pragma unroll
-            for (size_t i = 0; i < sizeof(EcDev) / 4; i++) dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
+            for (size_t i = 0; i < sizeof(EcDev) / 16; i++) {
+                const u32x4 v = src[i];
+                dst[4 * i + 0] = __builtin_amdgcn_readfirstlane(v.x);
+                dst[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
+                dst[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z);
+                dst[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
+            }
         }
         ec_dev_globalize(d, opaque);
         const int64_t hs = pol0.keep ? (int64_t)it : 0;  // history slot of this iteration's outputs
