@@ -15,6 +15,7 @@ Batching conventions (the reference's DGAIL runs one environment; everything bel
   * with torch.distributed every rank owns a shard of envs; gradients are averaged over ranks with one flat
     all-reduce per optimiser step, advantage normalisation uses the global mean / std.
 """
+import copy
 import os
 
 import numpy as np
@@ -29,7 +30,7 @@ from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import (DiffusionDiscrim
 from marl_amd.utils import mlp_device
 from marl_amd.utils.action_selectors import greedy_selector, soft_selector
 from marl_amd.utils.advantage_utils import get_gae
-from marl_amd.utils.dist_utils import all_reduce_grads_, broadcast_params_, global_mean, global_mean_std
+from marl_amd.utils.dist_utils import all_reduce_grads_, broadcast_params_, dist_on, global_mean, global_mean_std
 
 
 class DGAILAgent:
@@ -50,8 +51,13 @@ class DGAILAgent:
         self.gail_discriminator = GAILDiscriminator(self.state_action_dim, args.hidden_dim).to(self.device)
         broadcast_params_([self.policy, self.value, self.discriminator, self.gail_discriminator])
 
-        self.policy_optimizer = Adam(self.policy.parameters(), lr=args.policy_lr)
-        self.value_optimizer = Adam(self.value.parameters(), lr=args.value_lr)
+        # One hipGraph per full minibatch step of _update_policy (forward, joint loss, backward, both clipped Adam
+        # steps): at 64 steps per iteration of ~150 small launches each, the update is launch-bound otherwise.
+        # Single process only (the gradient all-reduce stays outside graphs); ec_graph_update=0 turns it off.
+        self._graph_update = (self.device.type == "cuda" and not dist_on() and bool(getattr(args, "ec_graph_update", 1)))
+        self._mb_graph = None
+        self.policy_optimizer = Adam(self.policy.parameters(), lr=args.policy_lr, capturable=self._graph_update)
+        self.value_optimizer = Adam(self.value.parameters(), lr=args.value_lr, capturable=self._graph_update)
         self.discriminator_optimizer = Adam(self.discriminator.parameters(), lr=args.discriminator_lr)
         self.gail_discriminator_optimizer = Adam(self.gail_discriminator.parameters(), lr=args.gail_discriminator_lr)
 
@@ -107,9 +113,10 @@ class DGAILAgent:
         self.expert_transitions.append(obs, actions, select)
 
     # ------------------------------------------------------------------ losses
-    def _compute_bc_loss(self):
+    def _compute_bc_loss(self, sample=None):
         """dgail_agent.py:151-168: cross entropy on `batch_expert_transitions` random expert transitions."""
-        obs, act = self.expert_transitions.sample_transitions(self.args.batch_expert_transitions)
+        obs, act = sample if sample is not None else self.expert_transitions.sample_transitions(
+            self.args.batch_expert_transitions)
         logits = self.policy(self._with_ids(obs).reshape(-1, self.policy_input_dim))
         return F.nll_loss(F.log_softmax(logits, dim=-1), act.reshape(-1), reduction="mean")
 
@@ -259,33 +266,102 @@ class DGAILAgent:
         rows = act_f.shape[0]
         mb = max(1, int(a.ppo_batch_size) * int(getattr(a, "n_threads", 1)))
         n_mb = (rows + mb - 1) // mb
-        totals = th.zeros(3, device=self.device)
+        bc_w = th.full((), float(self.bc_loss_weight), device=self.device)
+        graph = self._minibatch_graph(policy_input, act_f, log_probs_old, adv_f, ret_f, mb, bc_w) \
+            if (self._graph_update and rows >= mb) else None
+        totals = graph["totals"] if graph is not None else th.zeros(3, device=self.device)
         for _ in range(a.ppo_epochs):
             perm = th.randperm(rows, device=self.device)
             for i in range(n_mb):
                 idx = perm[i * mb:(i + 1) * mb]
-                x = policy_input[idx]
-                dist_new = th.distributions.Categorical(logits=self.policy(x))
-                log_probs_new = dist_new.log_prob(act_f[idx])
-                entropy = dist_new.entropy().mean()
-                ratio = th.exp(log_probs_new - log_probs_old[idx])
-                adv_b = adv_f[idx]
-                policy_loss = -th.min(ratio * adv_b, th.clamp(ratio, 1.0 - a.clip_param, 1.0 + a.clip_param) * adv_b).mean()
-                value_loss = ((self.value(x[:, :self.obs_shape]) - ret_f[idx]) ** 2).mean()
-                bc_loss = self._compute_bc_loss()
-                loss = (policy_loss - a.entropy_coef * entropy + a.value_loss_coef * value_loss
-                        + self.bc_loss_weight * bc_loss)
-                self.policy_optimizer.zero_grad()
-                self.value_optimizer.zero_grad()
-                loss.backward()
-                all_reduce_grads_(list(self.policy.parameters()) + list(self.value.parameters()), average=True)
-                th.nn.utils.clip_grad_norm_(self.policy.parameters(), a.grad_norm_clip)
-                th.nn.utils.clip_grad_norm_(self.value.parameters(), a.grad_norm_clip)
-                self.policy_optimizer.step()
-                self.value_optimizer.step()
-                totals += th.stack([policy_loss.detach(), value_loss.detach(), entropy.detach()])
+                bc = self.expert_transitions.sample_transitions(a.batch_expert_transitions)
+                if graph is not None and idx.shape[0] == mb and bc[1].shape == graph["bc_act"].shape:
+                    graph["idx"].copy_(idx)
+                    graph["bc_obs"].copy_(bc[0])
+                    graph["bc_act"].copy_(bc[1])
+                    graph["graph"].replay()
+                else:
+                    self._minibatch_step(policy_input, act_f, log_probs_old, adv_f, ret_f, idx, bc, bc_w, totals)
         totals = (totals / (a.ppo_epochs * n_mb)).tolist()
         return {"policy_loss": totals[0], "value_loss": totals[1], "entropy": totals[2]}
+
+    def _minibatch_step(self, policy_input, act_f, log_probs_old, adv_f, ret_f, idx, bc, bc_w, totals):
+        """One optimiser step of dgail_agent.py:283-325 on the rows `idx`; no host synchronisation (capturable)."""
+        a = self.args
+        x = policy_input[idx]
+        dist_new = th.distributions.Categorical(logits=self.policy(x), validate_args=False)
+        log_probs_new = dist_new.log_prob(act_f[idx])
+        entropy = dist_new.entropy().mean()
+        ratio = th.exp(log_probs_new - log_probs_old[idx])
+        adv_b = adv_f[idx]
+        policy_loss = -th.min(ratio * adv_b, th.clamp(ratio, 1.0 - a.clip_param, 1.0 + a.clip_param) * adv_b).mean()
+        value_loss = ((self.value(x[:, :self.obs_shape]) - ret_f[idx]) ** 2).mean()
+        bc_loss = self._compute_bc_loss(bc)
+        loss = policy_loss - a.entropy_coef * entropy + a.value_loss_coef * value_loss + bc_w * bc_loss
+        self.policy_optimizer.zero_grad()
+        self.value_optimizer.zero_grad()
+        loss.backward()
+        all_reduce_grads_(list(self.policy.parameters()) + list(self.value.parameters()), average=True)
+        th.nn.utils.clip_grad_norm_(self.policy.parameters(), a.grad_norm_clip)
+        th.nn.utils.clip_grad_norm_(self.value.parameters(), a.grad_norm_clip)
+        self.policy_optimizer.step()
+        self.value_optimizer.step()
+        totals += th.stack([policy_loss.detach(), value_loss.detach(), entropy.detach()])
+
+    def _minibatch_graph(self, policy_input, act_f, log_probs_old, adv_f, ret_f, mb, bc_w):
+        """Static copies of the iteration's tensors and one captured _minibatch_step over them.  The graph is
+        captured once per shape and reused by later iterations (inputs are copied into the same storage)."""
+        n_bc = min(int(self.args.batch_expert_transitions), len(self.expert_transitions))
+        key = (tuple(policy_input.shape), mb, n_bc)
+        g = self._mb_graph
+        if g is None or g["key"] != key:
+            dev = self.device
+            g = {"key": key, "policy_input": th.empty_like(policy_input), "act": th.empty_like(act_f),
+                 "logp": th.empty_like(log_probs_old), "adv": th.empty_like(adv_f), "ret": th.empty_like(ret_f),
+                 "idx": th.zeros(mb, dtype=th.long, device=dev),
+                 "bc_obs": th.zeros(n_bc, self.n_agents, self.obs_shape, device=dev),
+                 "bc_act": th.zeros(n_bc, self.n_agents, dtype=th.long, device=dev),
+                 "bc_w": th.zeros((), device=dev), "totals": th.zeros(3, device=dev), "graph": None}
+        for k, v in (("policy_input", policy_input), ("act", act_f), ("logp", log_probs_old), ("adv", adv_f),
+                     ("ret", ret_f), ("bc_w", bc_w)):
+            g[k].copy_(v)
+        if g["graph"] is None:
+            # a few eager steps on a side stream first (library handles, autograd buffers), with the networks and
+            # optimisers put back afterwards so that the step count stays the reference's; then one step is
+            # recorded (recording executes nothing)
+            rows = act_f.shape[0]
+            snap = [copy.deepcopy(m.state_dict()) for m in (self.policy, self.value, self.policy_optimizer,
+                                                            self.value_optimizer)]
+            side = th.cuda.Stream(device=self.device)
+            side.wait_stream(th.cuda.current_stream(self.device))
+            with th.cuda.stream(side):
+                for _ in range(3):
+                    idx = th.randint(0, rows, (mb,), device=self.device)
+                    bc = self.expert_transitions.sample_transitions(n_bc)
+                    self._minibatch_step(g["policy_input"], g["act"], g["logp"], g["adv"], g["ret"], idx, bc, g["bc_w"],
+                                         th.zeros(3, device=self.device))
+            th.cuda.current_stream(self.device).wait_stream(side)
+            th.cuda.synchronize(self.device)
+            for m, sd in zip((self.policy, self.value, self.policy_optimizer, self.value_optimizer), snap):
+                m.load_state_dict(sd)
+            # Adam creates its state lazily inside step(); created while recording, the zero-fills would be part of
+            # the graph and every replay would start from fresh moments
+            for opt in (self.policy_optimizer, self.value_optimizer):
+                for group in opt.param_groups:
+                    for prm in group["params"]:
+                        if len(opt.state[prm]) == 0:
+                            opt.state[prm] = {"step": th.zeros((), dtype=th.float32, device=prm.device),
+                                              "exp_avg": th.zeros_like(prm), "exp_avg_sq": th.zeros_like(prm)}
+            self.policy_optimizer.zero_grad(set_to_none=True)
+            self.value_optimizer.zero_grad(set_to_none=True)
+            graph = th.cuda.CUDAGraph()
+            with th.cuda.graph(graph):
+                self._minibatch_step(g["policy_input"], g["act"], g["logp"], g["adv"], g["ret"], g["idx"],
+                                     (g["bc_obs"], g["bc_act"]), g["bc_w"], g["totals"])
+            g["graph"] = graph
+            self._mb_graph = g
+        g["totals"].zero_()
+        return g
 
     def _bc_pretrain(self):
         """dgail_agent.py:520-534: `_bc_pretrain_steps` Adam(1e-3) steps, one random expert transition each."""

@@ -8,6 +8,34 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _chunked_tn(a, b, chunk):
+    """a^T @ b for tall a [rows, m], b [rows, n], reduced in row chunks (a batched GEMM + a small sum)."""
+    rows = a.shape[0]
+    full = (rows // chunk) * chunk
+    out = th.bmm(a[:full].reshape(-1, chunk, a.shape[1]).transpose(1, 2), b[:full].reshape(-1, chunk, b.shape[1])).sum(0)
+    if full < rows:
+        out = out + a[full:].t() @ b[full:]
+    return out
+
+
+class _TallMatmulFn(th.autograd.Function):
+    """gy @ w for tall gy: the input-gradient product of a Linear.  Differentiated again (the R1 penalty of the
+    diffusion discriminator differentiates through the first backward), its weight gradient is gy^T @ ggx with the
+    row count as the contraction length: chunked like the first-order one."""
+
+    @staticmethod
+    def forward(ctx, gy, w):
+        ctx.save_for_backward(gy, w)
+        return gy @ w
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        g_gy = ggx @ w.t() if ctx.needs_input_grad[0] else None
+        g_w = _chunked_tn(gy, ggx, _SplitKLinearFn.CHUNK) if ctx.needs_input_grad[1] else None
+        return g_gy, g_w
+
+
 class _SplitKLinearFn(th.autograd.Function):
     """y = x W^T + b whose weight gradient is reduced in row chunks (a batched GEMM + a small sum).  The stock
     backward hands [out, rows] x [rows, in] with rows ~ 10^5..10^6 to one GEMM without split-K: a handful of
@@ -25,7 +53,7 @@ class _SplitKLinearFn(th.autograd.Function):
         x, w = ctx.saved_tensors
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = gy @ w
+            gx = _TallMatmulFn.apply(gy, w) if th.is_grad_enabled() else gy @ w
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             rows = gy.shape[0]
             c = _SplitKLinearFn.CHUNK

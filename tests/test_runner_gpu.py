@@ -202,6 +202,56 @@ def test_dgail_runner_iterations():
     runner.close_env()
 
 
+def test_dgail_graphed_minibatch_step_equals_eager():
+    """The hipGraph of DGAIL's minibatch step (policy + value forward, joint loss, backward, two clipped Adam steps)
+    leaves the networks where the same step run eagerly leaves them, and capturing it does not move them."""
+    import copy
+    from marl_amd.agent_register import agent_register
+    B = 16
+    a = _imitation_args("dgail", B, episode_limit=20)
+    th.manual_seed(3)
+    g_agent = agent_register["dgail"](a)
+    a2 = copy.copy(a)
+    a2.ec_graph_update = 0
+    e_agent = agent_register["dgail"](a2)
+    assert g_agent._graph_update and not e_agent._graph_update
+    for m in ("policy", "value"):
+        getattr(e_agent, m).load_state_dict(getattr(g_agent, m).state_dict())
+    dev = g_agent.device
+    N, O = a.n_agents, a.obs_shape
+    rows, mb = B * 20 * N, 64 * B
+    for ag in (g_agent, e_agent):
+        ag.expert_transitions.append(th.rand(300, N, O, device=dev), th.randint(0, N + 1, (300, N), device=dev))
+    e_agent.expert_transitions.obs.copy_(g_agent.expert_transitions.obs)
+    e_agent.expert_transitions.actions.copy_(g_agent.expert_transitions.actions)
+    gen = th.Generator(device=dev).manual_seed(5)
+    pin = th.rand(rows, g_agent.policy_input_dim, device=dev, generator=gen)
+    act = th.randint(0, N + 1, (rows,), device=dev, generator=gen)
+    logp = -th.rand(rows, device=dev, generator=gen) * 3
+    adv = th.randn(rows, device=dev, generator=gen)
+    ret = th.randn(rows, 1, device=dev, generator=gen)
+    bc_w = th.full((), 0.3, device=dev)
+    before = copy.deepcopy(g_agent.policy.state_dict())
+    g = g_agent._minibatch_graph(pin, act, logp, adv, ret, mb, bc_w)
+    for k, v in g_agent.policy.state_dict().items():
+        assert th.equal(v, before[k]), k                       # warm-up and capture left the networks untouched
+    totals_e = th.zeros(3, device=dev)
+    for step in range(3):
+        idx = th.randperm(rows, device=dev, generator=gen)[:mb]
+        bc = g_agent.expert_transitions.sample_transitions(a.batch_expert_transitions)
+        g["idx"].copy_(idx)
+        g["bc_obs"].copy_(bc[0])
+        g["bc_act"].copy_(bc[1])
+        g["graph"].replay()
+        e_agent._minibatch_step(pin, act, logp, adv, ret, idx, bc, bc_w, totals_e)
+    assert th.allclose(g["totals"], totals_e, rtol=1e-4, atol=1e-6)
+    for m in ("policy", "value"):
+        for (k, p), (_, q) in zip(getattr(g_agent, m).state_dict().items(), getattr(e_agent, m).state_dict().items()):
+            assert th.allclose(p, q, rtol=1e-4, atol=1e-6), (m, k)
+    moved = sum(float((v - before[k]).abs().max()) for k, v in g_agent.policy.state_dict().items())
+    assert moved > 0
+
+
 def test_gail_runner_iterations():
     from marl_amd.agent_register import agent_register
     from marl_amd.runners.runner_register import runner_register
