@@ -100,7 +100,14 @@ class PPOAgent:
             rewards = (rewards - mean) / (std + 1e-5)
         old_logp, _ = ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, want_logp=True)
         old_v = ppo_device.critic_pass(self.critic, obs, masks, N, want_values=True).view(shape)
-        old_next_v = ppo_device.critic_pass(self.critic, next_obs, masks, N, want_values=True).view(shape)
+        if shape[1] > 1 and th.equal(next_obs[:, :-1], obs[:, 1:]):
+            # the runner stores one observation as next_obs[t] and obs[t+1]: V(next_obs[t]) is V(obs[t+1]) (the kernel
+            # evaluates rows independently, so the values are the same bits); only the last step needs a pass
+            last = ppo_device.critic_pass(self.critic, next_obs[:, -1:].contiguous(), masks[:, -1:].contiguous(), N,
+                                          want_values=True).view(shape[0], 1, *shape[2:])
+            old_next_v = th.cat([old_v[:, 1:], last], dim=1)
+        else:
+            old_next_v = ppo_device.critic_pass(self.critic, next_obs, masks, N, want_values=True).view(shape)
         advantages = get_gae(a, rewards, old_v, old_next_v, masks)
         if a.normalize_advantages:
             mean, std = global_mean_std(advantages)
