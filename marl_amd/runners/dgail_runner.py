@@ -32,32 +32,61 @@ class DGAILRunner:
         self._totals = th.zeros(6, dtype=th.float64, device=dev)
         self.expert_steps = 0  # expert-driven env steps of the last episode
         self._store = TransitionStore(self.env, self._totals)
+        # per-step expert ratios of the running episode and the count of expert-driven env steps, on the device: the
+        # episode below has no host-dependent values in it, so that it can be replayed from a hipGraph
+        self._ratios = th.ones(args.episode_limit, dtype=th.float32, device=dev)
+        self._n_expert = th.zeros((), dtype=th.int64, device=dev)
+        self._graphs = {}
 
-    def _expert_ratio(self):
+    def _ratio_at(self, t_env):
         """dgail_runner.py:30-38"""
-        if self.t_env < self.bc_guidance_steps:
+        if t_env < self.bc_guidance_steps:
             return 1.0
-        if self.t_env < self.expert_guidance_steps:
-            progress = (self.t_env - self.bc_guidance_steps) / (self.expert_guidance_steps - self.bc_guidance_steps)
+        if t_env < self.expert_guidance_steps:
+            progress = (t_env - self.bc_guidance_steps) / (self.expert_guidance_steps - self.bc_guidance_steps)
             return max(0.2, 0.9 * (1 - progress))
         return 0.2
 
-    def _use_expert(self, test_mode):
-        """bool [B]: which envs act on the expert this step (dgail_runner.py:46)"""
-        B = self.args.n_threads
-        if test_mode:
-            return None
-        return th.rand(B, device=self.env.device) < self._expert_ratio()
+    def _expert_ratio(self):
+        return self._ratio_at(self.t_env)
 
     def run(self, test_mode=False):
+        args, env = self.args, self.env
+        B, T = args.n_threads, args.episode_limit
+        if not test_mode:   # t_env advances by B per step (dgail_runner.py:46 reads it before each step)
+            self._ratios.copy_(th.tensor([self._ratio_at(self.t_env + t * B) for t in range(T)], dtype=th.float32))
+        # --ec_graph_rollout: the first episode of each kind runs eagerly (it warms every kernel in place), the second
+        # is recorded, and all from the second on replay the hipGraph
+        key = bool(test_mode)
+        graphed = (getattr(args, "ec_graph_rollout", False) and env.device.type == "cuda"
+                   and self._store.usable(self.agent.buffer))
+        if graphed and key in self._graphs:
+            if self._graphs[key] is None:
+                g = th.cuda.CUDAGraph()
+                th.cuda.synchronize(env.device)
+                with th.cuda.graph(g):
+                    self._episode(test_mode)
+                self._graphs[key] = g
+            self._graphs[key].replay()
+            if not test_mode:
+                self.agent.buffer.t = T
+        else:
+            self._episode(test_mode)
+            if graphed:
+                self._graphs[key] = None           # warmed: record at the next call
+        if not test_mode:
+            self.t_env += B * T
+        return self._finish(test_mode, T)
+
+    def _episode(self, test_mode):
         args, env = self.args, self.env
         B, N = args.n_threads, args.n_agents
         self.agent.buffer.reset()
         env.reset()
         env.observe()
         self._totals.zero_()
-        n_expert = th.zeros((), dtype=th.int64, device=env.device)
-        steps = 0
+        self._n_expert.zero_()
+        n_expert = self._n_expert
         fast = self._store.usable(self.agent.buffer)
         buf = None if test_mode else self.agent.buffer
         if fast and buf is not None:
@@ -69,7 +98,8 @@ class DGAILRunner:
                 self._obs.copy_(env.obs)
                 self._avail.copy_(env.avail)
                 obs, avail = self._obs, self._avail
-            use_expert = self._use_expert(test_mode)
+            # bool [B]: which envs act on the expert this step (dgail_runner.py:46)
+            use_expert = None if test_mode else th.rand(B, device=env.device) < self._ratios[t]
             agent_actions = self.agent.select_actions(obs, avail, test_mode)
             if use_expert is not None:
                 expert_actions = self.agent.get_expert_actions(env)
@@ -79,9 +109,6 @@ class DGAILRunner:
             else:
                 exec_actions = agent_actions
             reward, terminated, info = env.step(exec_actions, want_hops=(t == args.episode_limit - 1))
-            steps += 1
-            if not test_mode:
-                self.t_env += B
             if fast:
                 self._store.step(t, agent_actions, reward, terminated, info, buf)   # the buffer keeps the AGENT's action, :81
                 continue
@@ -92,6 +119,11 @@ class DGAILRunner:
                 rewards = reward.view(B, 1, 1).expand(B, N, 1)
                 masks = (1 - terminated.float()).view(B, 1, 1).expand(B, N, 1)
                 self.agent.buffer.insert(obs, avail, agent_actions.unsqueeze(-1), rewards, masks, env.obs)
+
+    def _finish(self, test_mode, steps):
+        args, env = self.args, self.env
+        B = args.n_threads
+        n_expert = self._n_expert
         env.check_status()
         totals = self._totals.clone()
         n_envs = th.tensor([float(B)], dtype=th.float64, device=totals.device)

@@ -24,15 +24,45 @@ class GAILRunner:
         self._avail = th.empty(B, N, args.n_actions, dtype=th.int, device=dev)
         self._totals = th.zeros(6, dtype=th.float64, device=dev)
         self._store = TransitionStore(self.env, self._totals)
+        self._ratio = th.zeros((), dtype=th.float32, device=dev)   # the episode's expert ratio, on the device
+        self._graphs = {}
 
     def run(self, test_mode=False, t_expert=0):
+        args, env = self.args, self.env
+        B, T = args.n_threads, args.episode_limit
+        guided = (not test_mode) and t_expert < args.expert_guidance_steps
+        if guided:
+            self._ratio.fill_(float(self.agent.get_expert_ratio(t_expert)))
+        # --ec_graph_rollout: the first episode of each kind runs eagerly (it warms every kernel in place), the second
+        # is recorded, and all from the second on replay the hipGraph
+        key = (bool(test_mode), bool(guided))
+        graphed = (getattr(args, "ec_graph_rollout", False) and env.device.type == "cuda"
+                   and self._store.usable(self.agent.buffer))
+        if graphed and key in self._graphs:
+            if self._graphs[key] is None:
+                g = th.cuda.CUDAGraph()
+                th.cuda.synchronize(env.device)
+                with th.cuda.graph(g):
+                    self._episode(test_mode, guided)
+                self._graphs[key] = g
+            self._graphs[key].replay()
+            if not test_mode:
+                self.agent.buffer.t = T
+        else:
+            self._episode(test_mode, guided)
+            if graphed:
+                self._graphs[key] = None           # warmed: record at the next call
+        if not test_mode:
+            self.t_env += B * T
+        return self._finish(test_mode)
+
+    def _episode(self, test_mode, guided):
         args, env = self.args, self.env
         B, N = args.n_threads, args.n_agents
         self.agent.buffer.reset()
         env.reset()
         env.observe()
         self._totals.zero_()
-        guided = (not test_mode) and t_expert < args.expert_guidance_steps
         fast = self._store.usable(self.agent.buffer)
         buf = None if test_mode else self.agent.buffer
         if fast and buf is not None:
@@ -46,15 +76,13 @@ class GAILRunner:
                 obs, avail = self._obs, self._avail
             agent_actions = self.agent.select_actions(obs, avail, test_mode)
             if guided:
-                use_expert = th.rand(B, device=env.device) < self.agent.get_expert_ratio(t_expert)
+                use_expert = th.rand(B, device=env.device) < self._ratio
                 expert_actions = self.agent.get_expert_actions(env)
                 exec_actions = th.where(use_expert.unsqueeze(-1), expert_actions, agent_actions)
                 self.agent.store_expert_data(obs, expert_actions, use_expert)     # :97-98 (obs is the pre-step one)
             else:
                 exec_actions = agent_actions
             reward, terminated, info = env.step(exec_actions, want_hops=(t == args.episode_limit - 1))
-            if not test_mode:
-                self.t_env += B
             if fast:
                 self._store.step(t, agent_actions, reward, terminated, info, buf)
                 continue
@@ -65,6 +93,10 @@ class GAILRunner:
                 rewards = reward.view(B, 1, 1).expand(B, N, 1)
                 masks = (1 - terminated.float()).view(B, 1, 1).expand(B, N, 1)
                 self.agent.buffer.insert(obs, avail, agent_actions.unsqueeze(-1), rewards, masks, env.obs)
+
+    def _finish(self, test_mode):
+        args, env = self.args, self.env
+        B = args.n_threads
         env.check_status()
         totals = self._totals.clone()
         n_envs = th.tensor([float(B)], dtype=th.float64, device=totals.device)

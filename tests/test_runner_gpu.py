@@ -202,6 +202,38 @@ def test_dgail_runner_iterations():
     runner.close_env()
 
 
+@pytest.mark.parametrize("kind", ["dgail", "gail"])
+def test_imitation_runner_graph_rollout(kind):
+    """--ec_graph_rollout for the expert-guided runners: eager first episode, recorded second, replayed afterwards;
+    every episode fills the buffer with masked agent actions, counts env steps and feeds the expert store."""
+    from marl_amd.agent_register import agent_register
+    from marl_amd.runners.runner_register import runner_register
+    B = 24
+    a = _imitation_args(kind, B, episode_limit=30, ec_graph_rollout=1)
+    th.manual_seed(4)
+    agent = agent_register[kind](a)
+    if kind == "dgail":
+        agent._bc_pretrain_steps = 5
+    runner = runner_register[kind + "_runner"](a, agent)
+    returns = []
+    for ep in range(4):
+        before = int(agent.expert_transitions._written.item())
+        info = runner.run(test_mode=False)
+        assert runner.t_env == (ep + 1) * B * a.episode_limit
+        assert agent.buffer.t == a.episode_limit
+        obs, avail, actions, rewards, masks, next_obs = agent.buffer.sample()
+        assert bool((avail.gather(-1, actions) == 1).all()), ep
+        assert th.equal(next_obs[:, :-1], obs[:, 1:])
+        assert int(agent.expert_transitions._written.item()) > before          # guidance ratio is > 0 this early
+        assert np.isfinite(info["episode_return"]) and 0 < info["success_rate"] <= 1
+        returns.append(info["episode_return"])
+    assert any(g is not None for g in runner._graphs.values())                 # episodes 3 and 4 were replays
+    assert len(set(returns)) == 4                                             # fresh random numbers in every replay
+    info = runner.run(test_mode=True)
+    assert runner.t_env == 4 * B * a.episode_limit and np.isfinite(info["success_rate"])
+    runner.close_env()
+
+
 def test_dgail_graphed_minibatch_step_equals_eager():
     """The hipGraph of DGAIL's minibatch step (policy + value forward, joint loss, backward, two clipped Adam steps)
     leaves the networks where the same step run eagerly leaves them, and capturing it does not move them."""

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--algo", default="dgail", choices=["gail", "dgail"])
     ap.add_argument("--envs", type=int, default=1024)
     ap.add_argument("--nodes", type=int, default=10)
-    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--diffusion-reward", action="store_true", help="DGAIL: use_simplified_reward=False")
     a = ap.parse_args()
     import torch as th
@@ -32,6 +32,7 @@ def main():
     ns = p.parse_args(["--task_size_max=6000", "--edge_node_num=%d" % a.nodes])
     ns.n_threads, ns.obs_shape, ns.n_agents, ns.n_actions = a.envs, 9, a.nodes, a.nodes + 1
     ns.state_shape, ns.device = 9 * a.nodes, "cuda"
+    ns.ec_graph_rollout = 1  # rollouts replay one hipGraph per episode from the third episode on
     if a.diffusion_reward:
         ns.use_simplified_reward = False
     th.manual_seed(100)
