@@ -32,12 +32,25 @@ __device__ __forceinline__ int kperm(int s, int half) {
 __device__ void stage_frag(float* __restrict__ dst, const float* __restrict__ w, int so, int si, int n_out, int K, int steps,
                            int TO, bool hidden_in) {
     const int total = steps * TO * 64;
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        const int c = idx & 3, l = (idx >> 2) & 63, rest = idx >> 8;
-        const int to = rest % TO, s = 4 * (rest / TO) + c;
-        const int half = l >> 5, out = 32 * to + (l & 31);
-        const int k = hidden_in ? kperm(s, half) : 2 * s + half;
-        dst[idx] = (out < n_out && k < K) ? w[(size_t)out * so + (size_t)k * si] : 0.0f;
+    // eight gathers in flight per thread before the first LDS store: one element per iteration costs one L2 round
+    // trip each (the whole staging of a 9-64-64-11 net was 28 of them, most of a 40 960-row launch)
+    constexpr int U = 8;
+    for (int base = threadIdx.x; base < total; base += U * blockDim.x) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int idx = base + u * (int)blockDim.x;
+            const int c = idx & 3, l = (idx >> 2) & 63, rest = idx >> 8;
+            const int to = rest % TO, s = 4 * (rest / TO) + c;
+            const int half = l >> 5, out = 32 * to + (l & 31);
+            const int k = hidden_in ? kperm(s, half) : 2 * s + half;
+            v[u] = (idx < total && out < n_out && k < K) ? w[(size_t)out * so + (size_t)k * si] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int idx = base + u * (int)blockDim.x;
+            if (idx < total) dst[idx] = v[u];
+        }
     }
 }
 
