@@ -1001,7 +1001,7 @@ struct StepCarry {
 
 // first: the lane's state comes from global memory (else from `cr` and the LDS arrays as the previous step left
 // them); last: it is written back.  One-step launches are both.
-template <int KMAX, int DMAX>
+template <int KMAX, int DMAX, bool EVX>
 __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restrict__ actions, float* __restrict__ reward,
                                           uint8_t* __restrict__ terminated, int32_t* __restrict__ counters,
                                           float* __restrict__ completion_time, float* __restrict__ next_obs,
@@ -1545,9 +1545,14 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
             }
 
             // (ii) is implicit: waiting time is c - enq.  (iii) the executing tasks, in order (:252-296)
+            // Integer bookkeeping in straight-line code for all slots.  EVX (the looping kernel): the fp64 reward /
+            // completion-time terms and the hop histogram of the slots that failed or finished are added afterwards,
+            // one event per lane per pass in slot order (the order of the reference's loop), as in receive_task
+            // below; the one-step kernel measured faster with them predicated in the slot loop.
             u32 keep = 0;
             {
                 const u32 n0 = ex_n;
+                u32 evx = 0, fbx = 0, sbx = 0;
 #pragma unroll
                 for (int s = 0; s < KMAX; s++) {
                     const bool act = (u32)s < n0;
@@ -1559,29 +1564,61 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                     const bool done = act && !fail && cet >= fin;
                     const bool succ = done && (exh[s] & KIND_SUCCESS);
                     const bool drop = done && !succ;
-                    const u32 hop = exh[s] & 0xffffu;
-#ifndef ABL_NO_REW
-                    rew = fail ? dadd(rew, d.pen_fail) : rew;
-                    rew = drop ? dadd(rew, d.pen_drop) : rew;
-                    rew = succ ? dadd(rew, d.rew_succ) : rew;
-                    rew = succ ? dadd(rew, hop > 1 ? dmul(d.pen_hop, (double)(hop - 1)) : 0.0) : rew;
-                    ct = done ? dadd(ct, exT[s]) : ct;
-#endif
                     n_fail += fail;
                     n_drop += drop;
                     n_succ += succ;
                     n_fin += (fail || done);
-                    if (succ) {
+                    if (!EVX) {
+                        const u32 hop = exh[s] & 0xffffu;
+                        rew = fail ? dadd(rew, d.pen_fail) : rew;
+                        rew = drop ? dadd(rew, d.pen_drop) : rew;
+                        rew = succ ? dadd(rew, d.rew_succ) : rew;
+                        rew = succ ? dadd(rew, hop > 1 ? dmul(d.pen_hop, (double)(hop - 1)) : 0.0) : rew;
+                        ct = done ? dadd(ct, exT[s]) : ct;
+                        if (succ) {
+                            u32 bin = hop;
+                            if (bin >= (u32)d.H) {
+                                bin = d.H - 1;
+                                flag(d, EC_ST_HOP_OVERFLOW);
+                            }
+                            atomicAdd(d.hop_hist + L.env * d.H + bin, 1);
+                        }
+                    }
+                    evx |= (fail || done) ? (1u << s) : 0u;
+                    fbx |= fail ? (1u << s) : 0u;
+                    sbx |= succ ? (1u << s) : 0u;
+                    const bool kp = act && !fail && !done;
+                    exw[s] = kp ? ((exw[s] & 0xffff0000u) | (cet > 0xfffeu ? 0xfffeu : cet)) : exw[s];
+                    keep |= kp ? (1u << s) : 0u;
+                }
+                while (EVX && evx) {
+                    const int s = __ffs((int)evx) - 1;
+                    evx &= evx - 1;
+                    if ((fbx >> s) & 1u) {
+                        rew = dadd(rew, d.pen_fail);
+                        continue;
+                    }
+                    u32 eh = 0;
+                    double eT = 0.0;
+#pragma unroll
+                    for (int q = 0; q < KMAX; q++) {
+                        eh = s == q ? exh[q] : eh;
+                        eT = s == q ? exT[q] : eT;
+                    }
+                    if ((sbx >> s) & 1u) {
+                        const u32 hop = eh & 0xffffu;
+                        rew = dadd(rew, d.rew_succ);
+                        rew = dadd(rew, hop > 1 ? dmul(d.pen_hop, (double)(hop - 1)) : 0.0);
                         u32 bin = hop;
                         if (bin >= (u32)d.H) {
                             bin = d.H - 1;
                             flag(d, EC_ST_HOP_OVERFLOW);
                         }
                         atomicAdd(d.hop_hist + L.env * d.H + bin, 1);
+                    } else {
+                        rew = dadd(rew, d.pen_drop);
                     }
-                    const bool kp = act && !fail && !done;
-                    exw[s] = kp ? ((exw[s] & 0xffff0000u) | (cet > 0xfffeu ? 0xfffeu : cet)) : exw[s];
-                    keep |= kp ? (1u << s) : 0u;
+                    ct = dadd(ct, eT);
                 }
                 if (keep != ((1u << n0) - 1)) {
                     // stable compaction of the survivors (executing_queue.remove keeps the order)
@@ -1953,7 +1990,7 @@ __global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem
                                               float* next_obs0, int32_t* next_avail0, StepPolicy pol0) {
     StepCarry<KMAX, DMAX> cr;
     if (!MULTI) {
-        step_body<KMAX, DMAX>(d_arg, actions0, reward0, terminated0, counters0, completion_time0, next_obs0, next_avail0,
+        step_body<KMAX, DMAX, false>(d_arg, actions0, reward0, terminated0, counters0, completion_time0, next_obs0, next_avail0,
                               pol0, cr, true, true);
         return;
     }
@@ -1989,7 +2026,7 @@ __global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem
         const u64 dbg_t0 = wall_clock64();
         dbg_gap += dbg_t0 - dbg_prev;
 #endif
-        step_body<KMAX, DMAX>(d, it == 0 ? actions0 : pol0.next_actions + (pol0.keep ? (int64_t)(it - 1) * d.P : 0),
+        step_body<KMAX, DMAX, true>(d, it == 0 ? actions0 : pol0.next_actions + (pol0.keep ? (int64_t)(it - 1) * d.P : 0),
                               reward0 ? reward0 + hs * d.B : nullptr, terminated0 ? terminated0 + hs * d.B : nullptr,
                               counters0 ? counters0 + hs * d.B * 4 : nullptr,
                               completion_time0 ? completion_time0 + hs * d.B : nullptr,
