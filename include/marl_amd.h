@@ -144,6 +144,26 @@ int ec_rollout_random_policy(ec_handle h, int32_t n_steps, int32_t keep_history,
                              float* next_obs, int32_t* next_avail, uint64_t seed, uint64_t counter,
                              int64_t* next_actions, void* stream);
 
+/* n_steps environment steps in ONE launch with the Actor acting inside the kernel: per step the rollout of
+ * ParallelRunner.run (runners/parallel_episode_runner.py:58-104) — agent.select_actions on the observation / mask
+ * (ppo_agent.py:60-74: Linear 9+N -> 64 -> 64 -> N+1 on [obs | one-hot agent], mask to -1e10, softmax, draw) followed by
+ * env.step and the next observation — without leaving the launch.  The actions equal ec_policy_forward's on the
+ * same weights, observation, mask and uniforms bit for bit, the env outputs ec_step's (the parity tests compare
+ * the per-step launches with this call).
+ *   w1 [64, 9+N], b1 [64], w2 [64,64], b2 [64], w3 [N+1, 64], b3 [N+1]   row-major fp32, as ec_policy_forward
+ *   uniforms [n_steps, B*N] in [0,1) for the inverse-CDF draw of step t, or NULL: greedy (first maximum)
+ *   obs0 [B,N,9], avail0 [B,N,N+1]   the observation the first action is chosen on (ec_observe)
+ *   actions [n_steps,B,N] i64 (out: the action taken at step t), reward [n_steps,B], terminated [n_steps,B],
+ *   counters [n_steps,B,4], completion_time [n_steps,B], next_obs [n_steps,B,N,9], next_avail [n_steps,B,N,N+1]:
+ *   slice t = outputs of step t; actions, next_obs, next_avail are required, the others may be NULL.  hop_hist
+ *   (cumulative) is copied once, after the last step.
+ * Compiled for k <= 4 parallel execution slots, in-degree <= 8 and N+1 <= 32 actions; EC_EINVAL otherwise (callers
+ * keep the per-step launches for those shapes). */
+int ec_rollout_mlp_policy(ec_handle h, int32_t n_steps, const float* w1, const float* b1, const float* w2, const float* b2,
+                          const float* w3, const float* b3, const float* uniforms, const float* obs0,
+                          const int32_t* avail0, int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
+                          float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail, void* stream);
+
 /* The expert of the GAIL / DGAIL runners for every env of the handle: OptimalAgent.get_current_optimal_action
  * (optimal/optimal_agent.py:102-120) = _conservative_action_selection at conservativeness 1.0 (:166-209) with the
  * reliability / time-margin / load / efficiency scores of :211-375, evaluated on the device state instead of walking
@@ -166,7 +186,8 @@ int ec_debug_rng_cursors(ec_handle h, uint64_t* cursors_host);
 int ec_debug_live_tasks(ec_handle h, int64_t* total_host);
 /* geometry chosen by ec_create: {B, N, k, D(max in-degree), cap_buffer, cap_recv, cap_wait, max_ticks,
  * threads_per_block, envs_per_block, state_bytes_lo, state_bytes_hi, lds_bytes_per_block, envs_per_wave,
- * main_waves, rng_producer_waves, rollout_kernel_resident}; the first n (<= 17) are written */
+ * main_waves, rng_producer_waves, rollout_kernel_resident, rollout_mlp_policy_available}; the first n (<= 18)
+ * are written */
 int ec_info(ec_handle h, int64_t* info_host, int32_t n);
 
 /* --- GAE: replaces utils/advantage_utils.py:4-9 ------------------------------------------------ */
@@ -231,6 +252,20 @@ int ec_store_transition(const float* obs, const int32_t* avail, const int64_t* a
                         int64_t n_envs, int32_t n_agents, int32_t obs_dim, int32_t n_actions, int64_t t,
                         int64_t episode_limit, float* buf_obs, int32_t* buf_avail, int64_t* buf_actions,
                         float* buf_rewards, float* buf_masks, float* buf_next_obs, double* totals, void* stream);
+
+/* ec_store_transition for a whole episode at once, from the time-major histories ec_rollout_mlp_policy (or
+ * ec_rollout_random_policy with keep_history) wrote: obs0 / avail0 = the observation before the first step; hist_*
+ * [T, ...] as documented there (hist_actions[t] = the action taken at step t).  Fills the [B,T,N,.] EpisodeBuffer
+ * tensors (buffer/episode_buffer.py:6-28; obs[:,0] = obs0, obs[:,t+1] = next_obs[:,t] = hist_obs[t]) and adds the
+ * episode's statistics to totals[6] in the order T ec_store_transition calls would (same bits).  buf_* all NULL:
+ * statistics only; totals NULL: buffer only.  partial [T,6] f64 and done (u32, zero on entry, left zero) are
+ * caller-provided scratch. */
+int ec_store_episode(const float* obs0, const int32_t* avail0, const float* hist_obs, const int32_t* hist_avail,
+                     const int64_t* hist_actions, const float* hist_reward, const uint8_t* hist_terminated,
+                     const int32_t* hist_counters, const float* hist_completion_time, int64_t n_envs, int32_t n_agents,
+                     int32_t obs_dim, int32_t n_actions, int64_t episode_limit, float* buf_obs, int32_t* buf_avail,
+                     int64_t* buf_actions, float* buf_rewards, float* buf_masks, float* buf_next_obs, double* totals,
+                     double* partial, uint32_t* done, void* stream);
 
 /* --- fused PPO loss + gradients ----------------------------------------------------------------------------------
  * One launch per network does the forward pass, the loss and the whole backward pass of the (obs | one-hot agent id)

@@ -143,6 +143,7 @@ def lib():
     L.ec_step.argtypes = [vp] + [vp] * 8 + [vp]
     L.ec_step_random_policy.argtypes = [vp] + [vp] * 8 + [u64, u64, vp, vp]
     L.ec_rollout_random_policy.argtypes = [vp, i32, i32] + [vp] * 8 + [u64, u64, vp, vp]
+    L.ec_rollout_mlp_policy.argtypes = [vp, i32] + [vp] * 18
     L.ec_random_policy.argtypes = [vp, i64, i32, u64, u64, vp, vp, vp]
     L.ec_expert_policy.argtypes = [vp, vp, vp, vp]
     L.ec_status.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, vp]
@@ -158,11 +159,12 @@ def lib():
     L.ec_ppo_actor_grad.argtypes = [vp] * 12 + [i64, i32, i32, i32, f32, f32, f32, vp, vp, vp, vp, vp]
     L.ec_ppo_critic_grad.argtypes = [vp] * 9 + [i64, i32, i32, f32, vp, vp, vp, vp]
     L.ec_store_transition.argtypes = [vp] * 7 + [i64, i32, i32, i32, i64, i64] + [vp] * 8
+    L.ec_store_episode.argtypes = [vp] * 9 + [i64, i32, i32, i32, i64] + [vp] * 10
     for fn in ("ec_create", "ec_destroy", "ec_reset", "ec_observe", "ec_step", "ec_random_policy", "ec_status",
                "ec_debug_dump", "ec_debug_rng_cursors", "ec_debug_live_tasks", "ec_info", "ec_gae",
                "ec_policy_forward", "ec_gail_reward", "ec_diffusion_reward", "ec_expert_policy",
-               "ec_ppo_actor_grad", "ec_ppo_critic_grad", "ec_store_transition",
-               "ec_step_random_policy", "ec_rollout_random_policy"):
+               "ec_ppo_actor_grad", "ec_ppo_critic_grad", "ec_store_transition", "ec_store_episode",
+               "ec_step_random_policy", "ec_rollout_random_policy", "ec_rollout_mlp_policy"):
         getattr(L, fn).restype = C.c_int
     L.ec_last_error.restype = C.c_char_p
     L.ec_version.restype = C.c_char_p

@@ -29,4 +29,9 @@ inline int fail(int code, const char* fmt, ...) {
             return ec::fail(EC_EHIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
     } while (0)
 
+// ec_mlp.hip: the Actor's weights in the fragment order of ec_policy_inline.h (one small launch), for the looping
+// env kernel of ec_rollout_mlp_policy.  dst holds polinl::staged_floats(n_agents) floats.
+int stage_policy(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                 int n_agents, int n_actions, float* dst, hipStream_t stream);
+
 }  // namespace ec

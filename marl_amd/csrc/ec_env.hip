@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "ec_common.h"
+#include "ec_policy_inline.h"
 
 namespace {
 
@@ -2046,6 +2047,115 @@ __global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem
 #endif
 }
 
+// ec_rollout_mlp_policy: the looping kernel with the Actor evaluated inside the launch.  Per step: every wave of the
+// block takes 32-row tiles of the block's rows through polinl::policy_tile (the observation and mask the previous
+// step wrote, or the caller's initial ones), the barrier publishes the actions to the main lanes, the step runs.
+// Outputs are always histories ([n_steps, ...]).
+struct MlpRollout {
+    const float* staged;    // polinl layout
+    const float* uniforms;  // [n_steps, B*N] or null (greedy)
+    const float* obs0;      // [B,N,9]   observation the first action is chosen on
+    const int32_t* avail0;  // [B,N,A]
+    int n_steps;
+};
+
+template <int KMAX, int DMAX>
+__global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpRollout m, int64_t* actions0, float* reward0,
+                                                     uint8_t* terminated0, int32_t* counters0, float* completion_time0,
+                                                     float* next_obs0, int32_t* next_avail0) {
+    StepCarry<KMAX, DMAX> cr;
+#ifdef EC_STAMPS
+    u64 dbg_pol = 0, dbg_wait = 0, dbg_body = 0, dbg_gap = 0, dbg_prev = wall_clock64();
+    u64* dbg_out = nullptr;
+#endif
+    for (int it = 0; it < m.n_steps; it++) {
+        size_t opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const EcDev* dp = d_mem + opaque;
+        EcDev d;
+        {
+            const u32x4* src = reinterpret_cast<const u32x4*>(dp);
+            u32* dst = reinterpret_cast<u32*>(&d);
+#pragma unroll
+            for (size_t i = 0; i < sizeof(EcDev) / 16; i++) {
+                const u32x4 v = src[i];
+                dst[4 * i + 0] = __builtin_amdgcn_readfirstlane(v.x);
+                dst[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
+                dst[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z);
+                dst[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
+            }
+        }
+        ec_dev_globalize(d, opaque);
+        int64_t* act = actions0 + (int64_t)it * d.P;
+#ifdef EC_STAMPS
+        dbg_out = d.stamps;
+        const u64 dbg_t0 = wall_clock64();
+        dbg_gap += dbg_t0 - dbg_prev;
+#endif
+        {
+            const float* ob = it == 0 ? m.obs0 : next_obs0 + (int64_t)(it - 1) * d.P * 9;
+            const int32_t* av = it == 0 ? m.avail0 : next_avail0 + (int64_t)(it - 1) * d.P * d.A;
+            const float* un = m.uniforms ? m.uniforms + (int64_t)it * d.P : nullptr;
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+            const int64_t row_base = (int64_t)blockIdx.x * d.epb * d.N;  // the block's rows are contiguous (lane_id)
+            const int64_t left = d.P - row_base;
+            const int nrows = left < (int64_t)d.epb * d.N ? (int)left : d.epb * d.N;
+#ifdef ABL_NO_POLICY
+            for (int i = threadIdx.x; i < nrows; i += blockDim.x) act[row_base + i] = d.N;
+            if (false)
+#endif
+            for (int t0 = wave * 32; t0 < nrows; t0 += nw * 32) {
+                const int nv = nrows - t0 < 32 ? nrows - t0 : 32;
+                if (d.A <= 16)
+                    polinl::policy_tile<2>(m.staged, ob, av, un, act, row_base + t0, nv, d.N, d.A, lane);
+                else
+                    polinl::policy_tile<4>(m.staged, ob, av, un, act, row_base + t0, nv, d.N, d.A, lane);
+            }
+        }
+#ifdef EC_STAMPS
+        const u64 dbg_t1 = wall_clock64();
+#endif
+        __syncthreads();  // the tiles' actions, written by whichever wave had the tile, to the lanes that take them
+        if (it > 0) {
+            const LaneId L = lane_id_main(d);
+            if (L.valid) cr.action = act[L.lane];
+        }
+#ifdef EC_STAMPS
+        const u64 dbg_t2 = wall_clock64();
+#endif
+        const int64_t hs = it;
+        step_body<KMAX, DMAX, true>(d, act, reward0 ? reward0 + hs * d.B : nullptr,
+                                    terminated0 ? terminated0 + hs * d.B : nullptr,
+                                    counters0 ? counters0 + hs * d.B * 4 : nullptr,
+                                    completion_time0 ? completion_time0 + hs * d.B : nullptr, next_obs0 + hs * d.P * 9,
+                                    next_avail0 + hs * d.P * d.A, StepPolicy{0, 0, nullptr, m.n_steps, 1}, cr, it == 0,
+                                    it + 1 == m.n_steps);
+#ifdef EC_STAMPS
+        dbg_prev = wall_clock64();
+        dbg_pol += dbg_t1 - dbg_t0;
+        dbg_wait += dbg_t2 - dbg_t1;
+        dbg_body += dbg_prev - dbg_t2;
+#endif
+        __syncthreads();
+    }
+#ifdef EC_STAMPS
+    if (threadIdx.x == 0 && dbg_out) {  // wave 0's totals: policy tile, wait for the other tiles + action, step, loop gap
+        dbg_out[(size_t)blockIdx.x * 16 + 9] = dbg_pol;
+        dbg_out[(size_t)blockIdx.x * 16 + 10] = dbg_wait;
+        dbg_out[(size_t)blockIdx.x * 16 + 11] = dbg_body;
+        dbg_out[(size_t)blockIdx.x * 16 + 12] = dbg_gap;
+    }
+#endif
+}
+
+typedef void (*rollout_mlp_fn)(const EcDev*, MlpRollout, int64_t*, float*, uint8_t*, int32_t*, float*, float*, int32_t*);
+rollout_mlp_fn pick_rollout_mlp(int k, int D) {  // the common shapes only: every instantiation is a full step kernel
+    if (k > 4) return nullptr;
+    if (D <= 4) return k_rollout_mlp<4, 4>;
+    if (D <= 8) return k_rollout_mlp<4, 8>;
+    return nullptr;
+}
+
 typedef void (*step_fn)(EcDev, const EcDev*, const int64_t*, float*, uint8_t*, int32_t*, float*, float*, int32_t*, StepPolicy);
 template <int KMAX, bool MULTI>
 step_fn pick_step_d(int D) {
@@ -2259,6 +2369,8 @@ struct ec_env {
     step_fn step_multi;  // the same kernel looping over steps (ec_rollout_random_policy)
     EcDev* d_dev;        // device copy of `d` for the looping kernel
     bool multi_resident; // every block of the looping kernel fits on the device at once
+    rollout_mlp_fn rollout_mlp;  // looping kernel with the Actor inside (ec_rollout_mlp_policy); null if not compiled for k / D
+    float* d_staged;     // its weight fragments (polinl layout)
     int kmax, dmax;
     std::vector<void*> allocs;
     size_t state_bytes;
@@ -2567,6 +2679,20 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
 #endif
 
     EC_TRY(dev_alloc(h, &h->d_dev, 1));
+    h->rollout_mlp = d.A <= 32 ? pick_rollout_mlp(d.k, D) : nullptr;
+    h->d_staged = nullptr;
+    if (h->rollout_mlp) {
+        EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->rollout_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->lds_step));
+        EC_TRY(dev_alloc(h, &h->d_staged, (size_t)polinl::staged_floats(N)));
+        if (getenv("MARL_AMD_EC_DEBUG")) {
+            int per_cu = 0;
+            EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(h->rollout_mlp),
+                                                                h->threads, h->lds_step));
+            fprintf(stderr, "rollout_mlp: %d blocks/CU, %lld blocks, %d CUs\n", per_cu, (long long)h->blocks,
+                    prop.multiProcessorCount);
+        }
+    }
     EC_HIP(hipMemcpy(h->d_dev, &d, sizeof(EcDev), hipMemcpyHostToDevice));
 
     const u32 ts = (u32)(cfg->task_seed + env_id_base), fs = (u32)(cfg->failure_seed + env_id_base);
@@ -2680,6 +2806,31 @@ int ec_rollout_random_policy(ec_handle h, int32_t n_steps, int32_t keep_history,
                      StepPolicy{seed, counter, next_actions, n_steps, keep_history ? 1 : 0}, stream);
 }
 
+int ec_rollout_mlp_policy(ec_handle h, int32_t n_steps, const float* w1, const float* b1, const float* w2, const float* b2,
+                          const float* w3, const float* b3, const float* uniforms, const float* obs0,
+                          const int32_t* avail0, int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
+                          float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail, void* stream) {
+    if (!h) return ec::fail(EC_EINVAL, "ec_rollout_mlp_policy: null handle");
+    if (n_steps < 1) return ec::fail(EC_EINVAL, "ec_rollout_mlp_policy: n_steps = %d", n_steps);
+    if (!obs0 || !avail0 || !actions || !next_obs || !next_avail)
+        return ec::fail(EC_EINVAL, "ec_rollout_mlp_policy: obs0, avail0, actions, next_obs and next_avail are required");
+    if (!h->rollout_mlp)
+        return ec::fail(EC_EINVAL, "ec_rollout_mlp_policy is compiled for k <= 4, in-degree <= 8, n_actions <= 32 (have k=%d, A=%d)",
+                        h->d.k, h->d.A);
+    const int rc = ec::stage_policy(w1, b1, w2, b2, w3, b3, h->d.N, h->d.A, h->d_staged, (hipStream_t)stream);
+    if (rc != EC_OK) return rc;
+    hipLaunchKernelGGL(h->rollout_mlp, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_step, (hipStream_t)stream,
+                       h->d_dev, MlpRollout{h->d_staged, uniforms, obs0, avail0, n_steps}, actions, reward, terminated,
+                       counters, completion_time, next_obs, next_avail);
+    if (hop_hist) {
+        const int64_t n = h->d.B * h->d.H;
+        hipLaunchKernelGGL(k_copy_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           h->d.hop_hist, hop_hist, n);
+    }
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}
+
 int ec_random_policy(const int32_t* avail, int64_t rows, int32_t n_actions, uint64_t seed, uint64_t counter,
                      uint64_t* counter_dev, int64_t* actions, void* stream) {
     if (!avail || !actions || rows < 0 || n_actions < 1) return ec::fail(EC_EINVAL, "bad argument");
@@ -2756,11 +2907,12 @@ int ec_debug_live_tasks(ec_handle h, int64_t* total_host) {
 
 int ec_info(ec_handle h, int64_t* info_host, int32_t n) {
     if (!h || !info_host) return ec::fail(EC_EINVAL, "null argument");
-    const int64_t v[17] = {h->d.B, h->d.N, h->d.k, h->d.D, h->d.capB, h->d.capR, h->d.capW, h->d.maxTicks,
+    const int64_t v[18] = {h->d.B, h->d.N, h->d.k, h->d.D, h->d.capB, h->d.capR, h->d.capW, h->d.maxTicks,
                            h->threads, h->envs_per_block, (int64_t)(h->state_bytes & 0xffffffffull),
                            (int64_t)(h->state_bytes >> 32), (int64_t)h->lds_step,
-                           h->d.epw, h->d.nmain / 64, (h->threads - h->d.nmain) / 64, h->multi_resident ? 1 : 0};
-    for (int i = 0; i < n && i < 17; i++) info_host[i] = v[i];
+                           h->d.epw, h->d.nmain / 64, (h->threads - h->d.nmain) / 64, h->multi_resident ? 1 : 0,
+                           h->rollout_mlp ? 1 : 0};
+    for (int i = 0; i < n && i < 18; i++) info_host[i] = v[i];
     return EC_OK;
 }
 

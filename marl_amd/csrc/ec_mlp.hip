@@ -27,6 +27,7 @@
 // The fp32 MFMA is an exact fmaf chain (MI355X_MICROARCH.md, "Matrix cores"), at the fp32 vector peak, without the
 // vector unit's LDS-broadcast traffic for weights (1 ds_read_b128 per 8 MFMAs here).
 #include "ec_mfma.h"
+#include "ec_policy_inline.h"
 
 namespace {
 
@@ -150,6 +151,28 @@ k_policy(const float* __restrict__ w1, const float* __restrict__ b1, const float
             }
             if (actions_out) actions_out[row] = pick;
         }
+    }
+}
+
+// The same fragments / biases / agent-id columns k_policy stages into LDS, written once to global memory for the
+// policy evaluation inside the looping env kernel (ec_policy_inline.h reads them in place).
+__global__ void __launch_bounds__(NT)
+k_stage_policy(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+               const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3, int n_agents, int A,
+               float* __restrict__ dst) {
+    static_assert(polinl::OBS == OBS && polinl::H == H, "ec_policy_inline.h is for the same net");
+    const int in1 = OBS + n_agents;
+    stage_frag(dst + polinl::F1, w1, in1, 1, H, OBS, 8, 2, false);
+    stage_frag(dst + polinl::F2, w2, H, 1, H, H, 32, 2, true);
+    stage_frag(dst + polinl::F3, w3, H, 1, A, H, 32, 1, true);
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        dst[polinl::B1 + i] = b1[i];
+        dst[polinl::B2 + i] = b2[i];
+    }
+    for (int i = threadIdx.x; i < 32; i += blockDim.x) dst[polinl::B3 + i] = i < A ? b3[i] : 0.0f;
+    for (int i = threadIdx.x; i < n_agents * H; i += blockDim.x) {
+        const int ag = i / H, o = i - ag * H;
+        dst[polinl::ID + i] = w1[(size_t)o * in1 + OBS + ag];
     }
 }
 
@@ -472,6 +495,16 @@ int blocks_per_cu(size_t lds) {
 }
 
 }  // namespace
+
+int ec::stage_policy(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                     int n_agents, int n_actions, float* dst, hipStream_t stream) {
+    if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !dst) return ec::fail(EC_EINVAL, "stage_policy: null weights");
+    if (n_actions < 1 || n_actions > 32 || n_agents < 1)
+        return ec::fail(EC_EINVAL, "in-kernel policy: n_actions = %d (supported: 1..32)", n_actions);
+    hipLaunchKernelGGL(k_stage_policy, dim3(1), dim3(NT), 0, stream, w1, b1, w2, b2, w3, b3, n_agents, n_actions, dst);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}
 
 extern "C" {
 

@@ -76,7 +76,118 @@ __global__ void __launch_bounds__(256) k_store(StoreArgs a) {
     if (threadIdx.x < 6) a.totals[threadIdx.x] += s[threadIdx.x][0];
 }
 
+// The same bookkeeping for a whole episode that ec_rollout_mlp_policy / ec_rollout_random_policy left as time-major
+// histories: one launch files every transition into the [B,T,N,.] buffer and adds the episode statistics.  The
+// statistics of step t are reduced by block t in k_store's order and added to the totals in step order by whichever
+// block finishes last, so the totals equal those of T ec_store_transition calls bit for bit.
+struct EpisodeArgs {
+    const float* obs0;          // [B,N,O]     observation before the first step
+    const int32_t* avail0;      // [B,N,A]
+    const float* h_obs;         // [T,B,N,O]   observation after step t
+    const int32_t* h_avail;     // [T,B,N,A]
+    const int64_t* h_actions;   // [T,B,N]     action taken at step t
+    const float* h_reward;      // [T,B]
+    const uint8_t* h_term;      // [T,B]
+    const int32_t* h_counters;  // [T,B,4]
+    const float* h_ctime;       // [T,B]
+    int64_t B;
+    int N, O, A;
+    int64_t T;
+    float* b_obs;
+    int32_t* b_avail;
+    int64_t* b_actions;
+    float* b_rewards;
+    float* b_masks;
+    float* b_next_obs;
+    double* totals;    // [6]
+    double* partial;   // [T,6] scratch
+    uint32_t* done;    // zero on entry, zero again on exit
+    int64_t copy_blocks;
+};
+
+__global__ void __launch_bounds__(256) k_store_episode(EpisodeArgs a) {
+    const int64_t P = a.B * a.N;
+    if ((int64_t)blockIdx.x < a.copy_blocks) {
+        const int64_t at = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, t, n) row of the buffer
+        if (at >= P * a.T) return;
+        const int n = (int)(at % a.N);
+        const int64_t bt = at / a.N;
+        const int64_t t = bt % a.T, b = bt / a.T;
+        const int64_t lane = b * a.N + n;
+        const float* nx = a.h_obs + (t * P + lane) * a.O;
+        const float* ob = t == 0 ? a.obs0 + lane * a.O : a.h_obs + ((t - 1) * P + lane) * a.O;
+        const int32_t* av = t == 0 ? a.avail0 + lane * a.A : a.h_avail + ((t - 1) * P + lane) * a.A;
+        for (int k = 0; k < a.O; k++) {
+            a.b_next_obs[at * a.O + k] = nx[k];
+            a.b_obs[at * a.O + k] = ob[k];
+        }
+        for (int k = 0; k < a.A; k++) a.b_avail[at * a.A + k] = av[k];
+        a.b_actions[at] = a.h_actions[t * P + lane];
+        a.b_rewards[at] = a.h_reward[t * a.B + b];                       // team reward, parallel_episode_runner.py:101
+        a.b_masks[at] = a.h_term[t * a.B + b] ? 0.0f : 1.0f;             // :102
+        return;
+    }
+    if (!a.totals) return;
+    const int64_t t = (int64_t)blockIdx.x - a.copy_blocks;
+    __shared__ double s[6][256];
+    __shared__ bool last;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t b = threadIdx.x; b < a.B; b += blockDim.x) {
+        acc[0] += (double)a.h_reward[t * a.B + b];
+        acc[1] += (double)a.h_ctime[t * a.B + b];
+        for (int q = 0; q < 4; q++) acc[2 + q] += (double)a.h_counters[4 * (t * a.B + b) + q];
+    }
+    for (int q = 0; q < 6; q++) s[q][threadIdx.x] = acc[q];
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int q = 0; q < 6; q++) s[q][threadIdx.x] += s[q][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) a.partial[t * 6 + threadIdx.x] = s[threadIdx.x][0];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(a.done, 1u) == (uint32_t)(a.T - 1);
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x < 6) {
+        double tot = a.totals[threadIdx.x];
+        for (int64_t i = 0; i < a.T; i++)
+            tot += __hip_atomic_load(a.partial + i * 6 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.totals[threadIdx.x] = tot;
+    }
+    if (threadIdx.x == 0) *a.done = 0;
+}
+
 }  // namespace
+
+extern "C" int ec_store_episode(const float* obs0, const int32_t* avail0, const float* hist_obs, const int32_t* hist_avail,
+                                const int64_t* hist_actions, const float* hist_reward, const uint8_t* hist_terminated,
+                                const int32_t* hist_counters, const float* hist_completion_time, int64_t n_envs,
+                                int32_t n_agents, int32_t obs_dim, int32_t n_actions, int64_t episode_limit,
+                                float* buf_obs, int32_t* buf_avail, int64_t* buf_actions, float* buf_rewards,
+                                float* buf_masks, float* buf_next_obs, double* totals, double* partial, uint32_t* done,
+                                void* stream) {
+    if (n_envs <= 0 || episode_limit <= 0) return EC_OK;
+    if (!hist_reward || !hist_terminated || !hist_counters || !hist_completion_time)
+        return ec::fail(EC_EINVAL, "ec_store_episode: null step history");
+    if (buf_obs && (!buf_avail || !buf_actions || !buf_rewards || !buf_masks || !buf_next_obs || !obs0 || !avail0 ||
+                    !hist_obs || !hist_avail || !hist_actions))
+        return ec::fail(EC_EINVAL, "ec_store_episode: incomplete buffer or observation history");
+    if (totals && (!partial || !done)) return ec::fail(EC_EINVAL, "ec_store_episode: totals need the partial / done scratch");
+    const int64_t rows = n_envs * n_agents * episode_limit;
+    const int64_t copy_blocks = buf_obs ? (rows + 255) / 256 : 0;
+    const int64_t blocks = copy_blocks + (totals ? episode_limit : 0);
+    if (blocks == 0) return EC_OK;
+    if (blocks > 0x7fffffffll) return ec::fail(EC_EINVAL, "ec_store_episode: %lld blocks", (long long)blocks);
+    EpisodeArgs a{obs0, avail0, hist_obs, hist_avail, hist_actions, hist_reward, hist_terminated, hist_counters,
+                  hist_completion_time, n_envs, n_agents, obs_dim, n_actions, episode_limit, buf_obs, buf_avail,
+                  buf_actions, buf_rewards, buf_masks, buf_next_obs, totals, partial, done, copy_blocks};
+    hipLaunchKernelGGL(k_store_episode, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}
 
 extern "C" int ec_store_transition(const float* obs, const int32_t* avail, const int64_t* actions, const float* reward,
                                    const uint8_t* terminated, const int32_t* counters, const float* completion_time,

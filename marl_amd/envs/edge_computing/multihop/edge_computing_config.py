@@ -50,6 +50,7 @@ _HIP_FLAGS = (
     ("ec_env_id_base", int, 0),  # first env id of this rank's shard (seeds are task_seed + env id + node)
     ("ec_graph_rollout", int, 0),  # 1: ParallelRunner replays one hipGraph per episode
     ("ec_torch_update", int, 0),   # 1: PPOAgent.train keeps the torch-autograd update instead of the fused kernels
+    ("ec_kernel_rollout", int, 1),  # ParallelRunner + PPO: the whole episode (Actor + env) in one launch when the env supports it
     ("ec_graph_update", int, 1),   # DGAIL: replay one hipGraph per minibatch step of the policy/value update (single process)
 )
 

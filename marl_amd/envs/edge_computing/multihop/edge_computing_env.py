@@ -167,6 +167,45 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
         self._obs_valid = False  # self.obs / self.avail were not written: observe() again before reading them
         return history
 
+    def rollout_mlp_policy(self, params, n_steps, uniforms=None, history=None, want_hops=False):
+        """n_steps x [Actor forward + mask + softmax + draw on the current observation, env step, next observation] in
+        one launch (ec_rollout_mlp_policy): what n_steps rounds of mlp_device.policy_forward + step leave behind,
+        bit for bit.  params = mlp_device.linear_params(actor); uniforms [n_steps, B*N] f32 (None: greedy).  The
+        current observation is taken from observe() if self.obs is stale.  history: dict of [n_steps, ...] tensors
+        as in rollout_random_policy (missing ones are allocated; actions[t] is the action taken AT step t).
+        Returns history."""
+        n_steps = int(n_steps)
+        B, N = self.n_envs, self.n_agents
+        if not self._obs_valid:
+            self.observe()
+        w = [t if (t.dtype == th.float32 and t.is_contiguous()) else t.detach().to(th.float32).contiguous() for t in params]
+        if any(t.device != self.device for t in w):
+            raise ValueError("policy parameters must be on the env's device")
+        if tuple(w[0].shape) != (64, 9 + N) or tuple(w[2].shape) != (64, 64) or tuple(w[4].shape) != (N + 1, 64):
+            raise ValueError("rollout_mlp_policy expects the 9+N -> 64 -> 64 -> N+1 Actor")
+        if uniforms is not None:
+            if (tuple(uniforms.shape) != (n_steps, B * N) or uniforms.dtype != th.float32 or not uniforms.is_contiguous()
+                    or uniforms.device != self.device):
+                raise ValueError("uniforms must be a contiguous float32 [n_steps, B*N] tensor on the env's device")
+        shapes = {"reward": ((n_steps, B), th.float32), "terminated": ((n_steps, B), th.uint8),
+                  "counters": ((n_steps, B, 4), th.int32), "completion_time": ((n_steps, B), th.float32),
+                  "obs": ((n_steps, B, N, 9), th.float32), "avail": ((n_steps, B, N, N + 1), th.int32),
+                  "actions": ((n_steps, B, N), th.int64)}
+        history = {} if history is None else history
+        for key, (shape, dtype) in shapes.items():
+            t = history.get(key)
+            if t is None:
+                history[key] = th.empty(shape, dtype=dtype, device=self.device)
+            elif tuple(t.shape) != shape or t.dtype != dtype or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("history['%s'] must be a contiguous %s tensor of shape %s on the env's device" % (key, dtype, shape))
+        _abi.check(self.lib.ec_rollout_mlp_policy(
+            self._h, n_steps, *[_ptr(t) for t in w], _ptr(uniforms) if uniforms is not None else None, _ptr(self.obs),
+            _ptr(self.avail), _ptr(history["actions"]), _ptr(history["reward"]), _ptr(history["terminated"]),
+            _ptr(history["counters"]), _ptr(history["completion_time"]), _ptr(self.hop_hist) if want_hops else None,
+            _ptr(history["obs"]), _ptr(history["avail"]), self._stream()), "ec_rollout_mlp_policy")
+        self._obs_valid = False  # self.obs / self.avail still hold the observation from before the rollout
+        return history
+
     def step(self, actions, want_hops=False, fuse_observe=True):
         """actions: int64 [B,N] device tensor.  Returns (reward[B] f32, terminated[B] u8, info) where info holds
         device tensors: the four counters of edge_computing_env.py:130-135 as columns of `counters`,
@@ -225,8 +264,8 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
         return st
 
     def info_geometry(self):
-        v = (C.c_int64 * 17)()
-        _abi.check(self.lib.ec_info(self._h, v, 17), "ec_info")
+        v = (C.c_int64 * 18)()
+        _abi.check(self.lib.ec_info(self._h, v, 18), "ec_info")
         keys = ("B", "N", "k", "D", "cap_buffer", "cap_recv", "cap_wait", "max_ticks", "threads_per_block",
                 "envs_per_block")
         out = {k: int(v[i]) for i, k in enumerate(keys)}
@@ -234,6 +273,7 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
         out["lds_bytes_per_block"] = int(v[12])
         out["envs_per_wave"], out["main_waves"], out["rng_producer_waves"] = int(v[13]), int(v[14]), int(v[15])
         out["rollout_kernel_resident"] = bool(v[16])
+        out["rollout_mlp_policy"] = bool(v[17])  # ec_rollout_mlp_policy is compiled for this k / in-degree / n_actions
         return out
 
     def debug_dump(self, env, max_rows=8192):

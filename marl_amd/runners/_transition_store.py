@@ -45,6 +45,23 @@ class TransitionStore:
                 e.n_envs, e.n_agents, e.obs_shape, e.n_actions, int(t), e.episode_limit, *[_p(x) for x in b],
                 _p(self.totals), C.c_void_p(th.cuda.current_stream(e.device).cuda_stream)), "ec_store_transition")
 
+    def episode(self, hist, obs0, avail0, buf):
+        """a whole episode from the time-major histories of env.rollout_mlp_policy (ec_store_episode): the buffer
+        (buf None: statistics only) and the totals, as episode_limit step() calls would leave them"""
+        e = self.env
+        b = [getattr(buf, k) for k in ("obs", "avail_actions", "actions", "rewards", "masks", "next_obs")] if buf is not None else [None] * 6
+        if getattr(self, "_partial", None) is None:
+            self._partial = th.zeros(e.episode_limit, 6, dtype=th.float64, device=e.device)
+            self._done = th.zeros(1, dtype=th.int32, device=e.device)
+        with th.cuda.device(e.device):
+            _abi.check(_abi.lib().ec_store_episode(
+                _p(obs0), _p(avail0), _p(hist["obs"]), _p(hist["avail"]), _p(hist["actions"]), _p(hist["reward"]),
+                _p(hist["terminated"]), _p(hist["counters"]), _p(hist["completion_time"]), e.n_envs, e.n_agents,
+                e.obs_shape, e.n_actions, e.episode_limit, *[_p(x) for x in b], _p(self.totals), _p(self._partial),
+                _p(self._done), C.c_void_p(th.cuda.current_stream(e.device).cuda_stream)), "ec_store_episode")
+        if buf is not None:
+            buf.t = e.episode_limit
+
     def initial(self, buf):
         """after reset + observe: obs[:, 0] / avail_actions[:, 0]"""
         self._call(-1, None, None, None, None, buf)

@@ -10,6 +10,12 @@ agent's buffer.  Env e of the batch is the reference's worker e (seeds task_seed
 Multi-GPU: each rank constructs the runner with its own `args.ec_env_id_base` shard; episode metrics are
 summed over ranks so that `episode_info` is the whole job's.
 
+`args.ec_kernel_rollout` (default on): with the PPO agent the whole episode — Actor forward, mask, softmax, draw, env
+step and next observation, episode_limit times — is ONE launch of the looping env kernel (ec_rollout_mlp_policy),
+followed by one launch that files the episode into the agent's buffer (ec_store_episode).  The uniforms of the
+categorical draws come from one torch.rand call per episode.  Falls back to the per-step launches when the env shape
+is outside what that kernel is compiled for.
+
 `args.ec_graph_rollout = True` captures one whole episode (reset, episode_limit x [policy, step, statistics, buffer
 insert]) in a hipGraph on first use and replays it afterwards: the rollout is launch-bound (~20 small launches per
 step), and replaying removes the host from the loop.  Kernels are warmed on a throw-away one-env instance first, so
@@ -40,6 +46,8 @@ class ParallelRunner:
         self._totals = th.zeros(6, dtype=th.float64, device=dev)
         self._graphs = {}
         self._store = TransitionStore(self.env, self._totals)
+        self._hist = None
+        self._uniforms = None
 
     def _select(self, env, obs, avail, test_mode):
         if self.args.algo_type == "rl":
@@ -82,6 +90,29 @@ class ParallelRunner:
             self.t_env += B * args.episode_limit
         return self._finish(test_mode)
 
+    def _kernel_rollout_ok(self):
+        ag = self.agent
+        if not getattr(self.args, "ec_kernel_rollout", 1) or self.args.algo_type != "rl":
+            return False
+        if not (hasattr(ag, "actor") and hasattr(ag, "_fused_policy_ok") and ag._fused_policy_ok()):
+            return False
+        if getattr(self, "_kernel_ok", None) is None:
+            self._kernel_ok = self.env.info_geometry()["rollout_mlp_policy"]
+        return self._kernel_ok
+
+    def _episode_kernel(self, test_mode):
+        """the episode as two launches: ec_rollout_mlp_policy, ec_store_episode"""
+        from marl_amd.utils import mlp_device
+        args, env = self.args, self.env
+        T = args.episode_limit
+        if self._uniforms is None:
+            self._uniforms = th.empty(T, args.n_threads * args.n_agents, dtype=th.float, device=env.device)
+        self._uniforms.uniform_()  # the reference's PPO always samples (ppo_agent.py:62); torch's device generator
+        self._hist = env.rollout_mlp_policy(mlp_device.linear_params(self.agent.actor), T, uniforms=self._uniforms,
+                                            history=self._hist, want_hops=True)
+        # env.obs / env.avail still hold the observation from before the first step
+        self._store.episode(self._hist, env.obs, env.avail, None if test_mode else self.agent.buffer)
+
     def _episode(self, test_mode):
         args, env = self.args, self.env
         B, N = args.n_threads, args.n_agents
@@ -91,6 +122,8 @@ class ParallelRunner:
         self._totals.zero_()
         fast = self._store.usable(self.agent.buffer)
         buf = None if test_mode else self.agent.buffer
+        if fast and self._kernel_rollout_ok():
+            return self._episode_kernel(test_mode)
         if fast and buf is not None:
             self._store.initial(buf)
         # all environments of the batch terminate together at episode_limit (edge_computing_env.py:139-142)

