@@ -202,13 +202,13 @@ def cpu_baseline(args_ns, tables, n_envs, budget_s):
 
 def ppo_iterations(ns, B, N, iters):
     """BASELINE.json's second figure: wall time of one PPO iteration = ParallelRunner.run(test_mode=False):
-    episode_limit steps of (fused policy kernel -> ec_step -> device buffer insert) for all B envs, then
-    PPOAgent.train() (reward normalisation, GAE kernel, `epochs` full-batch actor/critic updates)."""
+    the episode as one ec_rollout_mlp_policy launch (Actor + env step, episode_limit times, for all B envs) and one
+    ec_store_episode launch into the device buffer, then PPOAgent.train() (reward normalisation, GAE kernel, `epochs` full-batch actor/critic updates)."""
     import torch as th
     from marl_amd.agent_register import agent_register
     from marl_amd.runners.runner_register import runner_register
     ns.n_threads, ns.algo_type, ns.obs_shape, ns.n_agents, ns.n_actions = B, "rl", 9, N, N + 1
-    ns.ec_graph_rollout = True  # one hipGraph per episode, as the env-only leg above
+    ns.ec_graph_rollout = True  # only used where ec_rollout_mlp_policy is not compiled for the env shape
     th.manual_seed(100)
     agent = agent_register["ppo"](ns)
     runner = runner_register["parallel"](ns, agent)
@@ -230,12 +230,14 @@ def ppo_iterations(ns, B, N, iters):
         runner.run(test_mode=False)
         th.cuda.synchronize()
         total.append(time.perf_counter() - t0)
+    mode = "ec_rollout_mlp_policy" if runner._kernel_rollout_ok() else "per-step launches (hipGraph)"
     runner.close_env()
     total, upd = sorted(total[1:]), sorted(spans[1:])
     med = lambda v: v[len(v) // 2]
     return {"total_ms": 1e3 * med(total), "update_ms": 1e3 * med(upd), "rollout_ms": 1e3 * (med(total) - med(upd)),
             "iters": iters, "envs": B, "agents": N, "episode_limit": ns.episode_limit, "epochs": ns.epochs,
             "rows_per_update": B * N * ns.episode_limit,
+            "rollout": mode,
             "rollout_agent_steps_per_s": B * N * ns.episode_limit / (med(total) - med(upd))}
 
 

@@ -2057,6 +2057,7 @@ struct MlpRollout {
     const float* obs0;      // [B,N,9]   observation the first action is chosen on
     const int32_t* avail0;  // [B,N,A]
     int n_steps;
+    unsigned act_lds;       // byte offset, past the step's LDS, of the block's [epb*N] i32 action hand-off
 };
 
 template <int KMAX, int DMAX>
@@ -2104,12 +2105,14 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
             for (int i = threadIdx.x; i < nrows; i += blockDim.x) act[row_base + i] = d.N;
             if (false)
 #endif
+            extern __shared__ __align__(16) unsigned char smem_all[];
+            int* s_act = reinterpret_cast<int*>(smem_all + m.act_lds);
             for (int t0 = wave * 32; t0 < nrows; t0 += nw * 32) {
                 const int nv = nrows - t0 < 32 ? nrows - t0 : 32;
                 if (d.A <= 16)
-                    polinl::policy_tile<2>(m.staged, ob, av, un, act, row_base + t0, nv, d.N, d.A, lane);
+                    polinl::policy_tile<2>(m.staged, ob, av, un, act, s_act + t0, row_base + t0, nv, d.N, d.A, lane);
                 else
-                    polinl::policy_tile<4>(m.staged, ob, av, un, act, row_base + t0, nv, d.N, d.A, lane);
+                    polinl::policy_tile<4>(m.staged, ob, av, un, act, s_act + t0, row_base + t0, nv, d.N, d.A, lane);
             }
         }
 #ifdef EC_STAMPS
@@ -2117,8 +2120,9 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
 #endif
         __syncthreads();  // the tiles' actions, written by whichever wave had the tile, to the lanes that take them
         if (it > 0) {
+            extern __shared__ __align__(16) unsigned char smem_all[];
             const LaneId L = lane_id_main(d);
-            if (L.valid) cr.action = act[L.lane];
+            if (L.valid) cr.action = reinterpret_cast<const int*>(smem_all + m.act_lds)[L.lidx];  // lidx = row of the block
         }
 #ifdef EC_STAMPS
         const u64 dbg_t2 = wall_clock64();
@@ -2371,6 +2375,7 @@ struct ec_env {
     bool multi_resident; // every block of the looping kernel fits on the device at once
     rollout_mlp_fn rollout_mlp;  // looping kernel with the Actor inside (ec_rollout_mlp_policy); null if not compiled for k / D
     float* d_staged;     // its weight fragments (polinl layout)
+    size_t lds_rollout_mlp;
     int kmax, dmax;
     std::vector<void*> allocs;
     size_t state_bytes;
@@ -2682,13 +2687,15 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     h->rollout_mlp = d.A <= 32 ? pick_rollout_mlp(d.k, D) : nullptr;
     h->d_staged = nullptr;
     if (h->rollout_mlp) {
+        h->lds_rollout_mlp = ((h->lds_step + 15) & ~(size_t)15) + (size_t)epb * N * 4;  // + the action hand-off
+        if (h->lds_rollout_mlp > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_rollout_mlp);
         EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->rollout_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)h->lds_step));
+                                   (int)h->lds_rollout_mlp));
         EC_TRY(dev_alloc(h, &h->d_staged, (size_t)polinl::staged_floats(N)));
         if (getenv("MARL_AMD_EC_DEBUG")) {
             int per_cu = 0;
             EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(h->rollout_mlp),
-                                                                h->threads, h->lds_step));
+                                                                h->threads, h->lds_rollout_mlp));
             fprintf(stderr, "rollout_mlp: %d blocks/CU, %lld blocks, %d CUs\n", per_cu, (long long)h->blocks,
                     prop.multiProcessorCount);
         }
@@ -2819,8 +2826,9 @@ int ec_rollout_mlp_policy(ec_handle h, int32_t n_steps, const float* w1, const f
                         h->d.k, h->d.A);
     const int rc = ec::stage_policy(w1, b1, w2, b2, w3, b3, h->d.N, h->d.A, h->d_staged, (hipStream_t)stream);
     if (rc != EC_OK) return rc;
-    hipLaunchKernelGGL(h->rollout_mlp, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_step, (hipStream_t)stream,
-                       h->d_dev, MlpRollout{h->d_staged, uniforms, obs0, avail0, n_steps}, actions, reward, terminated,
+    hipLaunchKernelGGL(h->rollout_mlp, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_rollout_mlp, (hipStream_t)stream,
+                       h->d_dev, MlpRollout{h->d_staged, uniforms, obs0, avail0, n_steps,
+                                            (unsigned)((h->lds_step + 15) & ~(size_t)15)}, actions, reward, terminated,
                        counters, completion_time, next_obs, next_avail);
     if (hop_hist) {
         const int64_t n = h->d.B * h->d.H;

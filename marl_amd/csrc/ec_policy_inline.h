@@ -89,8 +89,8 @@ __device__ __forceinline__ void hidden_part(f32x16 (&out)[TO], const Frag<NS * T
 template <int NQ>
 __device__ __forceinline__ void policy_tile(const float* __restrict__ st, const float* __restrict__ obs,
                                             const int32_t* __restrict__ avail, const float* __restrict__ uniforms,
-                                            int64_t* __restrict__ actions, int64_t row0, int nvalid, int n_agents, int A,
-                                            int lane) {
+                                            int64_t* __restrict__ actions, int* __restrict__ actions_lds, int64_t row0,
+                                            int nvalid, int n_agents, int A, int lane) {
     const int jrow = lane & 31, half = lane >> 5;
     const bool live = jrow < nvalid;
     const int64_t row = row0 + (live ? jrow : 0);
@@ -99,6 +99,12 @@ __device__ __forceinline__ void policy_tile(const float* __restrict__ st, const 
     Frag<4> w1;
     Frag<8> wa, wb;
     w1.load(st + F1, 0, lane);
+    // the epilogue's inputs ride along with the first round of loads (the row's lane: half 0)
+    int32_t av[8 * NQ];
+    float u01 = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 8 * NQ; a++) av[a] = (live && !half && a < A) ? avail[row * A + a] : 1;
+    if (uniforms && live && !half) u01 = uniforms[row];
     float b[5];  // B operand of step s: input k = 2s + half of the lane's row (the 10th input is a zero column)
 #pragma unroll
     for (int s = 0; s < 5; s++) {
@@ -108,6 +114,8 @@ __device__ __forceinline__ void policy_tile(const float* __restrict__ st, const 
     acc_load<2>(h1, st + B1, half, false);
     acc_load<2>(h1, st + ID + agent * H, half, true);
     wa.load(st + F2, 0, lane);  // layer 2, s4 0..3
+    wb.load(st + F2, 8, lane);  // layer 2, s4 4..7
+    acc_load<2>(h2, st + B2, half, false);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s4 = 0; s4 < 2; s4++)
@@ -121,8 +129,6 @@ __device__ __forceinline__ void policy_tile(const float* __restrict__ st, const 
                 if (s < 5) h1[to] = mfma(av[c], b[s], h1[to]);
             }
         }
-    acc_load<2>(h2, st + B2, half, false);
-    wb.load(st + F2, 8, lane);  // layer 2, s4 4..7
     __builtin_amdgcn_sched_barrier(0);
     hidden_part<2, 0, 4>(h2, wa, h1);
     __builtin_amdgcn_sched_barrier(0);
@@ -150,7 +156,7 @@ __device__ __forceinline__ void policy_tile(const float* __restrict__ st, const 
 #pragma unroll
     for (int a = 0; a < 8 * NQ; a++) {
         if (a < A) {
-            if (avail[row * A + a] == 0) x[a] = -1e10f;
+            if (av[a] == 0) x[a] = -1e10f;
             mx = fmaxf(mx, x[a]);
         }
     }
@@ -165,7 +171,7 @@ __device__ __forceinline__ void policy_tile(const float* __restrict__ st, const 
     int pick = 0;
     if (uniforms) {
         // inverse CDF on the caller's uniform; zero-probability (masked) actions are never returned
-        const float u = uniforms[row] * sum;
+        const float u = u01 * sum;
         float c = 0.0f;
         int last = 0;
         bool found = false;
@@ -195,6 +201,7 @@ __device__ __forceinline__ void policy_tile(const float* __restrict__ st, const 
         }
     }
     actions[row] = pick;
+    if (actions_lds) actions_lds[row - row0] = pick;
 }
 
 }  // namespace polinl

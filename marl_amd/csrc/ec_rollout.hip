@@ -105,26 +105,35 @@ struct EpisodeArgs {
     int64_t copy_blocks;
 };
 
+constexpr int EP_TC = 10;  // steps per copy block of k_store_episode
+
 __global__ void __launch_bounds__(256) k_store_episode(EpisodeArgs a) {
-    const int64_t P = a.B * a.N;
     if ((int64_t)blockIdx.x < a.copy_blocks) {
-        const int64_t at = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, t, n) row of the buffer
-        if (at >= P * a.T) return;
-        const int n = (int)(at % a.N);
-        const int64_t bt = at / a.N;
-        const int64_t t = bt % a.T, b = bt / a.T;
-        const int64_t lane = b * a.N + n;
-        const float* nx = a.h_obs + (t * P + lane) * a.O;
-        const float* ob = t == 0 ? a.obs0 + lane * a.O : a.h_obs + ((t - 1) * P + lane) * a.O;
-        const int32_t* av = t == 0 ? a.avail0 + lane * a.A : a.h_avail + ((t - 1) * P + lane) * a.A;
-        for (int k = 0; k < a.O; k++) {
-            a.b_next_obs[at * a.O + k] = nx[k];
-            a.b_obs[at * a.O + k] = ob[k];
+        // one env, TC consecutive steps per block: the destination range of each tensor is contiguous over the whole
+        // chunk, the source one N*dim-element segment per step
+        const int64_t chunks = (a.T + EP_TC - 1) / EP_TC;
+        const int64_t b = (int64_t)blockIdx.x / chunks;
+        const int64_t t0 = ((int64_t)blockIdx.x - b * chunks) * EP_TC;
+        const int nt = (int)(a.T - t0 < EP_TC ? a.T - t0 : EP_TC);
+        const int NO = a.N * a.O, NA = a.N * a.A;
+        for (int i = threadIdx.x; i < nt * NO; i += blockDim.x) {
+            const int tt = i / NO, k = i - tt * NO;
+            const int64_t t = t0 + tt, dst = (b * a.T + t) * NO + k;
+            a.b_next_obs[dst] = a.h_obs[(t * a.B + b) * NO + k];
+            a.b_obs[dst] = t == 0 ? a.obs0[b * NO + k] : a.h_obs[((t - 1) * a.B + b) * NO + k];
         }
-        for (int k = 0; k < a.A; k++) a.b_avail[at * a.A + k] = av[k];
-        a.b_actions[at] = a.h_actions[t * P + lane];
-        a.b_rewards[at] = a.h_reward[t * a.B + b];                       // team reward, parallel_episode_runner.py:101
-        a.b_masks[at] = a.h_term[t * a.B + b] ? 0.0f : 1.0f;             // :102
+        for (int i = threadIdx.x; i < nt * NA; i += blockDim.x) {
+            const int tt = i / NA, k = i - tt * NA;
+            const int64_t t = t0 + tt;
+            a.b_avail[(b * a.T + t) * NA + k] = t == 0 ? a.avail0[b * NA + k] : a.h_avail[((t - 1) * a.B + b) * NA + k];
+        }
+        for (int i = threadIdx.x; i < nt * a.N; i += blockDim.x) {
+            const int tt = i / a.N, n = i - tt * a.N;
+            const int64_t t = t0 + tt, dst = (b * a.T + t) * a.N + n;
+            a.b_actions[dst] = a.h_actions[(t * a.B + b) * a.N + n];
+            a.b_rewards[dst] = a.h_reward[t * a.B + b];                  // team reward, parallel_episode_runner.py:101
+            a.b_masks[dst] = a.h_term[t * a.B + b] ? 0.0f : 1.0f;        // :102
+        }
         return;
     }
     if (!a.totals) return;
@@ -176,8 +185,7 @@ extern "C" int ec_store_episode(const float* obs0, const int32_t* avail0, const 
                     !hist_obs || !hist_avail || !hist_actions))
         return ec::fail(EC_EINVAL, "ec_store_episode: incomplete buffer or observation history");
     if (totals && (!partial || !done)) return ec::fail(EC_EINVAL, "ec_store_episode: totals need the partial / done scratch");
-    const int64_t rows = n_envs * n_agents * episode_limit;
-    const int64_t copy_blocks = buf_obs ? (rows + 255) / 256 : 0;
+    const int64_t copy_blocks = buf_obs ? n_envs * ((episode_limit + EP_TC - 1) / EP_TC) : 0;
     const int64_t blocks = copy_blocks + (totals ? episode_limit : 0);
     if (blocks == 0) return EC_OK;
     if (blocks > 0x7fffffffll) return ec::fail(EC_EINVAL, "ec_store_episode: %lld blocks", (long long)blocks);

@@ -77,7 +77,8 @@ class ParallelRunner:
     def run(self, test_mode=False):
         args, env = self.args, self.env
         B = args.n_threads
-        if getattr(args, "ec_graph_rollout", False):
+        kernel = self._store.usable(self.agent.buffer) and self._kernel_rollout_ok()  # two launches: nothing to replay
+        if getattr(args, "ec_graph_rollout", False) and not kernel:
             g = self._graphs.get(bool(test_mode))
             if g is None:
                 g = self._graphs[bool(test_mode)] = self._capture(test_mode)
