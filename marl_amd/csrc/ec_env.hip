@@ -2047,17 +2047,16 @@ __global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem
 #endif
 }
 
-// ec_rollout_mlp_policy: the looping kernel with the Actor evaluated inside the launch.  Per step: every wave of the
-// block takes 32-row tiles of the block's rows through polinl::policy_tile (the observation and mask the previous
-// step wrote, or the caller's initial ones), the barrier publishes the actions to the main lanes, the step runs.
-// Outputs are always histories ([n_steps, ...]).
+// ec_rollout_mlp_policy: the looping kernel with the Actor evaluated inside the launch.  Per step: every main wave
+// takes the rows of its own lanes through polinl::policy_rows (the observation and mask the previous step wrote, or
+// the caller's initial ones), then the step runs.  Outputs are always histories ([n_steps, ...]).
 struct MlpRollout {
     const float* staged;    // polinl layout
     const float* uniforms;  // [n_steps, B*N] or null (greedy)
     const float* obs0;      // [B,N,9]   observation the first action is chosen on
     const int32_t* avail0;  // [B,N,A]
     int n_steps;
-    unsigned act_lds;       // byte offset, past the step's LDS, of the block's [epb*N] i32 action hand-off
+    unsigned b23_lds;       // byte offset, past the step's LDS, of the layer-2/3 biases ([64] + [32] f32)
 };
 
 template <int KMAX, int DMAX>
@@ -2069,6 +2068,10 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
     u64 dbg_pol = 0, dbg_wait = 0, dbg_body = 0, dbg_gap = 0, dbg_prev = wall_clock64();
     u64* dbg_out = nullptr;
 #endif
+    extern __shared__ __align__(16) unsigned char smem_all[];
+    float* s_b23 = reinterpret_cast<float*>(smem_all + m.b23_lds);
+    for (int i = threadIdx.x; i < polinl::H + 32; i += blockDim.x) s_b23[i] = m.staged[polinl::B2 + i];
+    __syncthreads();
     for (int it = 0; it < m.n_steps; it++) {
         size_t opaque = 0;
         asm volatile("" : "+s"(opaque));
@@ -2094,38 +2097,34 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
         dbg_gap += dbg_t0 - dbg_prev;
 #endif
         {
+            // Every main wave evaluates the Actor on the rows of its own lanes (lane l of the wave <-> row r0 + l of
+            // the block), so the action lands in the lane that takes it: no hand-off and no barrier, and the RNG
+            // producer waves go straight into the step to stage its draws while the policy runs.
             const float* ob = it == 0 ? m.obs0 : next_obs0 + (int64_t)(it - 1) * d.P * 9;
             const int32_t* av = it == 0 ? m.avail0 : next_avail0 + (int64_t)(it - 1) * d.P * d.A;
             const float* un = m.uniforms ? m.uniforms + (int64_t)it * d.P : nullptr;
-            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-            const int64_t row_base = (int64_t)blockIdx.x * d.epb * d.N;  // the block's rows are contiguous (lane_id)
-            const int64_t left = d.P - row_base;
-            const int nrows = left < (int64_t)d.epb * d.N ? (int)left : d.epb * d.N;
-#ifdef ABL_NO_POLICY
-            for (int i = threadIdx.x; i < nrows; i += blockDim.x) act[row_base + i] = d.N;
-            if (false)
-#endif
-            extern __shared__ __align__(16) unsigned char smem_all[];
-            int* s_act = reinterpret_cast<int*>(smem_all + m.act_lds);
-            for (int t0 = wave * 32; t0 < nrows; t0 += nw * 32) {
-                const int nv = nrows - t0 < 32 ? nrows - t0 : 32;
-                if (d.A <= 16)
-                    polinl::policy_tile<2>(m.staged, ob, av, un, act, s_act + t0, row_base + t0, nv, d.N, d.A, lane);
-                else
-                    polinl::policy_tile<4>(m.staged, ob, av, un, act, s_act + t0, row_base + t0, nv, d.N, d.A, lane);
+            int pick = -1;
+            if ((int)threadIdx.x < d.nmain) {  // wave-uniform
+                const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                const int64_t row_base = (int64_t)blockIdx.x * d.epb * d.N;  // the block's rows are contiguous (lane_id)
+                const int64_t left = d.P - row_base;
+                const int nrows = left < (int64_t)d.epb * d.N ? (int)left : d.epb * d.N;
+                const int per = d.epw > 0 ? d.epw * d.N : 64;  // rows of a main wave (lane_id_main)
+                const int r0 = wave * per;
+                const int cnt = nrows - r0 < per ? nrows - r0 : per;
+                if (cnt > 32) {
+                    pick = d.A <= 16 ? polinl::policy_rows<2, 2>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane)
+                                     : polinl::policy_rows<4, 2>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
+                } else if (cnt > 0) {
+                    pick = d.A <= 16 ? polinl::policy_rows<2, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane)
+                                     : polinl::policy_rows<4, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
+                }
             }
+            if (it > 0) cr.action = pick;  // the first step reads act[] (this lane's own store)
         }
 #ifdef EC_STAMPS
         const u64 dbg_t1 = wall_clock64();
-#endif
-        __syncthreads();  // the tiles' actions, written by whichever wave had the tile, to the lanes that take them
-        if (it > 0) {
-            extern __shared__ __align__(16) unsigned char smem_all[];
-            const LaneId L = lane_id_main(d);
-            if (L.valid) cr.action = reinterpret_cast<const int*>(smem_all + m.act_lds)[L.lidx];  // lidx = row of the block
-        }
-#ifdef EC_STAMPS
-        const u64 dbg_t2 = wall_clock64();
+        const u64 dbg_t2 = dbg_t1;
 #endif
         const int64_t hs = it;
         step_body<KMAX, DMAX, true>(d, act, reward0 ? reward0 + hs * d.B : nullptr,
@@ -2687,7 +2686,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     h->rollout_mlp = d.A <= 32 ? pick_rollout_mlp(d.k, D) : nullptr;
     h->d_staged = nullptr;
     if (h->rollout_mlp) {
-        h->lds_rollout_mlp = ((h->lds_step + 15) & ~(size_t)15) + (size_t)epb * N * 4;  // + the action hand-off
+        h->lds_rollout_mlp = ((h->lds_step + 15) & ~(size_t)15) + (polinl::H + 32) * sizeof(float);  // + layer-2/3 biases
         if (h->lds_rollout_mlp > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_rollout_mlp);
         EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->rollout_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lds_rollout_mlp));

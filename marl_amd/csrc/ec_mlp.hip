@@ -172,7 +172,7 @@ k_stage_policy(const float* __restrict__ w1, const float* __restrict__ b1, const
     for (int i = threadIdx.x; i < 32; i += blockDim.x) dst[polinl::B3 + i] = i < A ? b3[i] : 0.0f;
     for (int i = threadIdx.x; i < n_agents * H; i += blockDim.x) {
         const int ag = i / H, o = i - ag * H;
-        dst[polinl::ID + i] = w1[(size_t)o * in1 + OBS + ag];
+        dst[polinl::BI + i] = b1[o] + w1[(size_t)o * in1 + OBS + ag];  // k_policy: acc = b1; acc += column
     }
 }
 

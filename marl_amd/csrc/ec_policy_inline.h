@@ -1,5 +1,5 @@
-// ec_policy_inline.h — the Actor forward + mask + softmax + sampling of ec_mlp.hip's k_policy for ONE tile of 32 rows
-// by ONE wave, callable from inside another kernel (the looping env kernel evaluates the policy between two steps
+// ec_policy_inline.h — the Actor forward + mask + softmax + sampling of ec_mlp.hip's k_policy for up to 64 rows by ONE
+// wave, callable from inside another kernel (the looping env kernel evaluates the policy between two steps
 // without leaving the launch).  Same arithmetic as k_policy, operation for operation (ppo_network.py:21-25,
 // ppo_agent.py:61-74, utils/action_selectors.py:11-20): every accumulator sees the same v_mfma_f32_32x32x2_f32 chain
 // in the same order, the epilogue the same max / expf / running sums — so the actions equal k_policy's bit for bit.
@@ -24,8 +24,8 @@ constexpr int F3 = F2 + 32 * 2 * 64;  // layer 3: 32 steps x 1 tile (n_actions <
 constexpr int B1 = F3 + 32 * 1 * 64;
 constexpr int B2 = B1 + H;
 constexpr int B3 = B2 + H;            // [32], zero beyond n_actions
-constexpr int ID = B3 + 32;           // [n_agents][64]: the one-hot agent-id columns of W1
-__host__ __device__ constexpr int staged_floats(int n_agents) { return ID + n_agents * H; }
+constexpr int BI = B3 + 32;           // [n_agents][64]: b1 + the agent's one-hot column of W1 (the bias an agent's rows start from)
+__host__ __device__ constexpr int staged_floats(int n_agents) { return BI + n_agents * H; }
 
 __device__ __forceinline__ float relu(float x) { return x > 0.0f ? x : 0.0f; }
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
@@ -53,7 +53,7 @@ __device__ __forceinline__ void acc_load(f32x16 (&acc)[TO], const float* __restr
         }
 }
 
-// Weight fragments of eight k-steps (two s4 groups) x TO tiles: 2*TO 16-byte loads per lane, issued together.
+// N4 consecutive 16-byte fragment words per lane, issued together
 template <int N4>
 struct Frag {
     float4 v[N4];
@@ -63,14 +63,15 @@ struct Frag {
     }
 };
 
-// s4 groups [S0, S0 + NS) of a hidden layer from fragments already in registers (w.v[(s4 - S0) * TO + to])
-template <int TO, int S0, int NS>
-__device__ __forceinline__ void hidden_part(f32x16 (&out)[TO], const Frag<NS * TO>& w, const f32x16 (&in)[2]) {
+// NS consecutive s4 groups, starting at S0, of a hidden layer with TO output tiles from fragment words
+// w.v[(s4 - W0) * TO + to]
+template <int TO, int S0, int NS, int W0, int NW>
+__device__ __forceinline__ void hidden_part(f32x16 (&out)[TO], const Frag<NW>& w, const f32x16 (&in)[2]) {
 #pragma unroll
     for (int s4 = S0; s4 < S0 + NS; s4++) {
 #pragma unroll
         for (int to = 0; to < TO; to++) {
-            const float4 a = w.v[(s4 - S0) * TO + to];
+            const float4 a = w.v[(s4 - W0) * TO + to];
             const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -81,41 +82,42 @@ __device__ __forceinline__ void hidden_part(f32x16 (&out)[TO], const Frag<NS * T
     }
 }
 
-// rows row0 .. row0+nvalid-1 (nvalid <= 32) of obs [rows, 9] / avail [rows, A] -> actions[row]; one full wave.
-// uniforms: one per row for the inverse-CDF draw, or null for the greedy choice.  A <= 8 * NQ <= 32.
-// The weight loads are staged by hand, a layer (or half of one) ahead of the MFMAs that use them, between
-// scheduling barriers: left alone, the compiler hoists all 28 of them to the top and spills 112 registers per lane
-// to scratch, which at 2048 resident waves is more memory traffic than the env step itself.
-template <int NQ>
-__device__ __forceinline__ void policy_tile(const float* __restrict__ st, const float* __restrict__ obs,
-                                            const int32_t* __restrict__ avail, const float* __restrict__ uniforms,
-                                            int64_t* __restrict__ actions, int* __restrict__ actions_lds, int64_t row0,
-                                            int nvalid, int n_agents, int A, int lane) {
+// The Actor on rows row0 .. row0+cnt-1 (cnt <= 32 G) of obs [rows, 9] / avail [rows, A] by one full wave; lane l
+// returns the action of row row0 + l (and writes it to actions[row0 + l]); -1 beyond cnt.  uniforms: one per row for
+// the inverse-CDF draw, or null for the greedy choice.  A <= 8 NQ <= 32.  s_b23: the biases of layers 2 and 3
+// ([64] + [32]) in LDS.
+// A memory round trip costs ~2 us next to the env step's traffic, several times the 106 MFMAs of a 32-row group, so
+// the order of things is about round trips: the fragments of layers 1 and 2, the observation inputs and the first
+// layer's bias (+ agent-id column, one precombined vector per agent) of BOTH groups are requested up front in one
+// round; layer 3's fragments, the mask and the uniform follow while layer 2 runs; nothing else touches global
+// memory.  Scheduling barriers pin that order (left alone, the compiler hoists every load to the top and spills a
+// hundred registers per lane to scratch).  G = 2 runs its two 32-row groups one after the other on the same
+// fragments.
+template <int NQ, int G>
+__device__ __forceinline__ int policy_rows(const float* __restrict__ st, const float* s_b23,
+                                           const float* __restrict__ obs, const int32_t* __restrict__ avail,
+                                           const float* __restrict__ uniforms, int64_t* __restrict__ actions,
+                                           int64_t row0, int cnt, int n_agents, int A, int lane) {
     const int jrow = lane & 31, half = lane >> 5;
-    const bool live = jrow < nvalid;
-    const int64_t row = row0 + (live ? jrow : 0);
-    const int agent = live ? (int)((uint32_t)(row % n_agents)) : 0;
-    f32x16 h1[2], h2[2], lg[1];
+    f32x16 h1[G][2];
+    float b[G][5];  // B operand of step s: input k = 2s + half of the group's row (the 10th input is a zero column)
     Frag<4> w1;
-    Frag<8> wa, wb;
+    Frag<16> w2;
+    Frag<8> w3;
     w1.load(st + F1, 0, lane);
-    // the epilogue's inputs ride along with the first round of loads (the row's lane: half 0)
-    int32_t av[8 * NQ];
-    float u01 = 0.0f;
 #pragma unroll
-    for (int a = 0; a < 8 * NQ; a++) av[a] = (live && !half && a < A) ? avail[row * A + a] : 1;
-    if (uniforms && live && !half) u01 = uniforms[row];
-    float b[5];  // B operand of step s: input k = 2s + half of the lane's row (the 10th input is a zero column)
+    for (int g = 0; g < G; g++) {
+        const bool live = 32 * g + jrow < cnt;
+        const int64_t row = row0 + (live ? 32 * g + jrow : 0);
+        const int agent = live ? (int)((uint32_t)row % (uint32_t)n_agents) : 0;  // rows < 2^31 (ec_create)
 #pragma unroll
-    for (int s = 0; s < 5; s++) {
-        const int k = 2 * s + half;
-        b[s] = (live && k < OBS) ? obs[row * OBS + k] : 0.0f;
+        for (int s = 0; s < 5; s++) {
+            const int k = 2 * s + half;
+            b[g][s] = (live && k < OBS) ? obs[row * OBS + k] : 0.0f;
+        }
+        acc_load<2>(h1[g], st + BI + agent * H, half, false);
     }
-    acc_load<2>(h1, st + B1, half, false);
-    acc_load<2>(h1, st + ID + agent * H, half, true);
-    wa.load(st + F2, 0, lane);  // layer 2, s4 0..3
-    wb.load(st + F2, 8, lane);  // layer 2, s4 4..7
-    acc_load<2>(h2, st + B2, half, false);
+    w2.load(st + F2, 0, lane);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s4 = 0; s4 < 2; s4++)
@@ -126,31 +128,50 @@ __device__ __forceinline__ void policy_tile(const float* __restrict__ st, const 
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int s = 4 * s4 + c;
-                if (s < 5) h1[to] = mfma(av[c], b[s], h1[to]);
+                if (s < 5) {
+#pragma unroll
+                    for (int g = 0; g < G; g++) h1[g][to] = mfma(av[c], b[g][s], h1[g][to]);
+                }
             }
         }
     __builtin_amdgcn_sched_barrier(0);
-    hidden_part<2, 0, 4>(h2, wa, h1);
+    // second round, behind layer 2 of the first group: layer 3's fragments and the epilogue's inputs.  Lane l is the
+    // lane of row row0 + l (G = 2); lanes 0..31 those of the only group (G = 1)
+    w3.load(st + F3, 0, lane);
+    const bool mine = G == 2 ? lane < cnt : (!half && jrow < cnt);
+    const int64_t myrow = row0 + (mine ? lane : 0);
+    int32_t av[8 * NQ];
+    float u01 = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 8 * NQ; a++) av[a] = (mine && a < A) ? avail[myrow * A + a] : 1;
+    if (uniforms && mine) u01 = uniforms[myrow];
     __builtin_amdgcn_sched_barrier(0);
-    wa.load(st + F3, 0, lane);  // layer 3, all of it
-    acc_load<1>(lg, st + B3, half, false);
-    __builtin_amdgcn_sched_barrier(0);
-    hidden_part<2, 4, 4>(h2, wb, h1);
-    __builtin_amdgcn_sched_barrier(0);
-    hidden_part<1, 0, 8>(lg, wa, h2);
-
-    // logits of the row: output 8q + 4*half' + c sits in register 4q + c of the lane of half'
     float x[8 * NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++)
+    for (int g = 0; g < G; g++) {
+        f32x16 h2[2], lg[1];
+        acc_load<2>(h2, s_b23, half, false);
+        hidden_part<2, 0, 8, 0, 16>(h2, w2, h1[g]);
+        __builtin_amdgcn_sched_barrier(0);
+        acc_load<1>(lg, s_b23 + H, half, false);
+        hidden_part<1, 0, 8, 0, 8>(lg, w3, h2);
+        // Output 8q + 4h + c of the group's row j sits in register 4q + c of lane (j, h); the row's lane is (j, 0)
+        // for G = 1 and (j, g) for G = 2: it keeps the four outputs of its own half and receives the other four
+        // from the lane 32 away.
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const float mine = lg[0][4 * q + c];
-            const float other = __shfl_xor(mine, 32);
-            x[8 * q + c] = half ? other : mine;
-            x[8 * q + 4 + c] = half ? mine : other;
-        }
-    if (half || !live) return;
+        for (int q = 0; q < NQ; q++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float own = lg[0][4 * q + c];
+                const float recv = __shfl_xor(own, 32);
+                if (G == 1 || half == g) {
+                    x[8 * q + c] = half ? recv : own;
+                    x[8 * q + 4 + c] = half ? own : recv;
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!mine) return -1;
     // actor_outs[avail == 0] = -1e10 ; softmax ; sample (ppo_agent.py:69-73)
     float mx = -3.0e38f;
 #pragma unroll
@@ -200,8 +221,8 @@ __device__ __forceinline__ void policy_tile(const float* __restrict__ st, const 
             }
         }
     }
-    actions[row] = pick;
-    if (actions_lds) actions_lds[row - row0] = pick;
+    actions[myrow] = pick;
+    return pick;
 }
 
 }  // namespace polinl
