@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Small driver for rocprofv3: N eager steps of the bench workload (policy kernel + ec_step), or -- 4th argument
-"rollout" -- the same steps through ec_rollout_random_policy, one launch per episode."""
+"rollout" -- the same steps through ec_rollout_random_policy, one launch per episode; "mlp" -- through
+ec_rollout_mlp_policy (random Actor weights)."""
 import os
 import sys
 
@@ -24,6 +25,19 @@ if len(sys.argv) > 4 and sys.argv[4] == "rollout":
         env.observe()
         env.random_actions(seed=0, counter=ep, out=act)
         env.rollout_random_policy(act, env.episode_limit, seed=0)
+    th.cuda.synchronize()
+    print("status", env.status(), "live/env", env.live_tasks() / B)
+    sys.exit(0)
+if len(sys.argv) > 4 and sys.argv[4] == "mlp":
+    gen = th.Generator().manual_seed(1)
+    dims = [(64, 9 + N), (64,), (64, 64), (64,), (N + 1, 64), (N + 1,)]
+    params = tuple((th.randn(*d, generator=gen) * (0.3 if len(d) == 2 else 0.1)).to(env.device) for d in dims)
+    hist = None
+    for ep in range(max(1, steps // env.episode_limit)):
+        env.reset()
+        env.observe()
+        u = th.rand(env.episode_limit, B * N, device=env.device)
+        hist = env.rollout_mlp_policy(params, env.episode_limit, uniforms=u, history=hist)
     th.cuda.synchronize()
     print("status", env.status(), "live/env", env.live_tasks() / B)
     sys.exit(0)
