@@ -420,6 +420,70 @@ def test_lockstep_launch_geometries(oracle_lib, monkeypatch, epw, mw, producers)
     b_env.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("epw,mw,producers", [(4, 1, 1), (6, 1, 1), (2, 2, 1), (3, 1, 0), (1, 4, 0), (5, 2, 1)])
+def test_rollout_mlp_policy_launch_geometries(monkeypatch, epw, mw, producers):
+    """The in-kernel Actor under every kind of launch geometry: one or two 32-row groups per main wave (3-6 envs of
+    10 nodes), several main waves, with and without an RNG producer wave, a partly filled last block — against the
+    per-step launches of a default-geometry env."""
+    th = _th()
+    from marl_amd.utils import mlp_device
+    g = load_golden("env10")
+    args = args_from_golden(g)
+    N, B, K = args.edge_node_num, 37, 25
+    ref_env = _make_env(args, B, 4)
+    monkeypatch.setenv("MARL_AMD_EC_EPW", str(epw))
+    monkeypatch.setenv("MARL_AMD_EC_MW", str(mw))
+    monkeypatch.setenv("MARL_AMD_EC_PRODUCERS", str(producers))
+    env = _make_env(args, B, 4)
+    geo = env.info_geometry()
+    assert (geo["envs_per_wave"], geo["main_waves"], geo["rng_producer_waves"] > 0) == (epw, mw, bool(producers))
+    assert geo["rollout_mlp_policy"]
+    dev = env.device
+    gen = th.Generator().manual_seed(99)
+    dims = [(64, 9 + N), (64,), (64, 64), (64,), (N + 1, 64), (N + 1,)]
+    params = tuple((th.randn(*d, generator=gen) * (0.6 if len(d) == 2 else 0.2)).to(dev) for d in dims)
+    for e in (ref_env, env):
+        e.reset()
+        e.observe()
+    for chunk in range(2):
+        u = th.rand(K, B * N, generator=gen).to(dev)
+        ref = {key: [] for key in ("reward", "counters", "obs", "avail", "actions")}
+        for i in range(K):
+            _, _, a = mlp_device.policy_forward(params, ref_env.obs, N, ref_env.avail, u[i], want_probs=False)
+            a = a.view(B, N)
+            r, term, info = ref_env.step(a)
+            for key, val in (("reward", r), ("counters", info["counters"]), ("obs", ref_env.obs),
+                             ("avail", ref_env.avail), ("actions", a)):
+                ref[key].append(val.clone())
+        hist = env.rollout_mlp_policy(params, K, uniforms=u)
+        for key in ref:
+            assert th.equal(th.stack(ref[key]), hist[key]), (chunk, key)
+    assert np.array_equal(ref_env.debug_dump(B - 1), env.debug_dump(B - 1))
+    assert np.array_equal(ref_env.debug_rng_cursors(), env.debug_rng_cursors())
+    for e in (ref_env, env):
+        assert e.status() & ~32 == 0
+        e.close()
+
+
+@pytest.mark.gpu
+def test_rollout_mlp_policy_unsupported_shape_is_an_error():
+    """40 nodes = 41 actions: outside what the in-kernel Actor is compiled for; the entry point says so (the runner
+    keeps the per-step launches there)."""
+    th = _th()
+    from marl_amd import _abi
+    g = load_golden("env40")
+    args = args_from_golden(g)
+    N = args.edge_node_num
+    env = _make_env(args, 3, 0)
+    assert not env.info_geometry()["rollout_mlp_policy"]
+    params = tuple(th.zeros(*d, device=env.device) for d in [(64, 9 + N), (64,), (64, 64), (64,), (N + 1, 64), (N + 1,)])
+    env.reset()
+    with pytest.raises(_abi.EcError):
+        env.rollout_mlp_policy(params, 2)
+    env.close()
+
+
 def test_lockstep_env_wider_than_a_wave(oracle_lib):
     """80 nodes: one env spans two main waves (contiguous lane mapping, two producer waves)."""
     from tests.util import make_args
