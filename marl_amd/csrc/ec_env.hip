@@ -953,6 +953,7 @@ struct StepPolicy {
     // ec_rollout_random_policy: the kernel takes n_steps steps, each fed by the actions its predecessor drew.
     // keep = 0: every step overwrites the same [B,...] outputs; keep = 1: outputs are [n_steps,B,...] histories.
     int n_steps, keep;
+    unsigned dev_lds;  // looping kernel: LDS byte offset of a block-local copy of the geometry block (0: none)
 };
 
 __device__ __forceinline__ u64 policy_hash(u64 seed, u64 counter, u64 rows, u64 r) {
@@ -2001,6 +2002,12 @@ __global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem
 #ifdef EC_STAMPS
     u64 dbg_prev = wall_clock64(), dbg_gap = 0, dbg_body = 0;
 #endif
+    extern __shared__ __align__(16) unsigned char smem_all[];
+    if (pol0.dev_lds) {  // the block's own copy of the geometry block: re-reading it is then not a memory round trip
+        for (int i = threadIdx.x; i < (int)(sizeof(EcDev) / 16); i += blockDim.x)
+            reinterpret_cast<u32x4*>(smem_all + pol0.dev_lds)[i] = reinterpret_cast<const u32x4*>(d_mem)[i];
+        __syncthreads();
+    }
     for (int it = 0; it < pol0.n_steps; it++) {
         size_t opaque = 0;  // an offset the compiler cannot see through: *dp is loaded anew in every iteration
         asm volatile("" : "+s"(opaque));
@@ -2008,15 +2015,27 @@ __global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem
         EcDev d;
         {   // uniform words: into SGPRs (a plain copy would sit in ~150 VGPRs)
             static_assert(sizeof(EcDev) % 16 == 0, "EcDev is copied in 16-byte pieces");
-            const u32x4* src = reinterpret_cast<const u32x4*>(dp);
             u32* dst = reinterpret_cast<u32*>(&d);
+            if (pol0.dev_lds) {
+                const u32x4* src = reinterpret_cast<const u32x4*>(smem_all + pol0.dev_lds) + opaque;
 #pragma unroll
-            for (size_t i = 0; i < sizeof(EcDev) / 16; i++) {
-                const u32x4 v = src[i];
-                dst[4 * i + 0] = __builtin_amdgcn_readfirstlane(v.x);
-                dst[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
-                dst[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z);
-                dst[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
+                for (size_t i = 0; i < sizeof(EcDev) / 16; i++) {
+                    const u32x4 v = src[i];
+                    dst[4 * i + 0] = __builtin_amdgcn_readfirstlane(v.x);
+                    dst[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
+                    dst[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z);
+                    dst[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
+                }
+            } else {
+                const u32x4* src = reinterpret_cast<const u32x4*>(dp);
+#pragma unroll
+                for (size_t i = 0; i < sizeof(EcDev) / 16; i++) {
+                    const u32x4 v = src[i];
+                    dst[4 * i + 0] = __builtin_amdgcn_readfirstlane(v.x);
+                    dst[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
+                    dst[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z);
+                    dst[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
+                }
             }
         }
         ec_dev_globalize(d, opaque);
@@ -2057,6 +2076,7 @@ struct MlpRollout {
     const int32_t* avail0;  // [B,N,A]
     int n_steps;
     unsigned b23_lds;       // byte offset, past the step's LDS, of the layer-2/3 biases ([64] + [32] f32)
+    unsigned dev_lds;       // byte offset of a block-local copy of the geometry block, or 0: re-read it from global memory
 };
 
 template <int KMAX, int DMAX>
@@ -2071,6 +2091,9 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
     extern __shared__ __align__(16) unsigned char smem_all[];
     float* s_b23 = reinterpret_cast<float*>(smem_all + m.b23_lds);
     for (int i = threadIdx.x; i < polinl::H + 32; i += blockDim.x) s_b23[i] = m.staged[polinl::B2 + i];
+    if (m.dev_lds)  // the geometry block, re-read every iteration (see k_step): from LDS it is not a memory round trip
+        for (int i = threadIdx.x; i < (int)(sizeof(EcDev) / 16); i += blockDim.x)
+            reinterpret_cast<u32x4*>(smem_all + m.dev_lds)[i] = reinterpret_cast<const u32x4*>(d_mem)[i];
     __syncthreads();
     for (int it = 0; it < m.n_steps; it++) {
         size_t opaque = 0;
@@ -2078,15 +2101,27 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
         const EcDev* dp = d_mem + opaque;
         EcDev d;
         {
-            const u32x4* src = reinterpret_cast<const u32x4*>(dp);
             u32* dst = reinterpret_cast<u32*>(&d);
+            if (m.dev_lds) {
+                const u32x4* src = reinterpret_cast<const u32x4*>(smem_all + m.dev_lds) + opaque;
 #pragma unroll
-            for (size_t i = 0; i < sizeof(EcDev) / 16; i++) {
-                const u32x4 v = src[i];
-                dst[4 * i + 0] = __builtin_amdgcn_readfirstlane(v.x);
-                dst[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
-                dst[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z);
-                dst[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
+                for (size_t i = 0; i < sizeof(EcDev) / 16; i++) {
+                    const u32x4 v = src[i];
+                    dst[4 * i + 0] = __builtin_amdgcn_readfirstlane(v.x);
+                    dst[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
+                    dst[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z);
+                    dst[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
+                }
+            } else {
+                const u32x4* src = reinterpret_cast<const u32x4*>(dp);
+#pragma unroll
+                for (size_t i = 0; i < sizeof(EcDev) / 16; i++) {
+                    const u32x4 v = src[i];
+                    dst[4 * i + 0] = __builtin_amdgcn_readfirstlane(v.x);
+                    dst[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
+                    dst[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z);
+                    dst[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
+                }
             }
         }
         ec_dev_globalize(d, opaque);
@@ -2372,9 +2407,12 @@ struct ec_env {
     step_fn step_multi;  // the same kernel looping over steps (ec_rollout_random_policy)
     EcDev* d_dev;        // device copy of `d` for the looping kernel
     bool multi_resident; // every block of the looping kernel fits on the device at once
+    size_t lds_step_multi;   // its dynamic LDS: lds_step + (if it fits) a copy of the geometry block at multi_dev_lds
+    unsigned multi_dev_lds;
     rollout_mlp_fn rollout_mlp;  // looping kernel with the Actor inside (ec_rollout_mlp_policy); null if not compiled for k / D
     float* d_staged;     // its weight fragments (polinl layout)
     size_t lds_rollout_mlp;
+    unsigned mlp_dev_lds;  // LDS offset of the looping kernel's copy of the geometry block (0: none)
     int kmax, dmax;
     std::vector<void*> allocs;
     size_t state_bytes;
@@ -2674,9 +2712,22 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
                                (int)h->lds_step));
     {   // the looping kernel is correct at any residency (blocks are independent), but a second round doubles its time
         int per_cu = 0;
-        EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(h->step_multi),
-                                                            h->threads, h->lds_step));
+        const void* fn_multi = reinterpret_cast<const void*>(h->step_multi);
+        EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn_multi, h->threads, h->lds_step));
         h->multi_resident = h->blocks <= (int64_t)per_cu * prop.multiProcessorCount;
+        // + a block-local copy of the geometry block behind the step's LDS, if that does not cost a resident block
+        h->lds_step_multi = h->lds_step;
+        h->multi_dev_lds = 0;
+        const size_t at = (h->lds_step + 15) & ~(size_t)15, more = at + sizeof(EcDev);
+        if (more <= 160 * 1024) {
+            int with = 0;
+            EC_HIP(hipFuncSetAttribute(fn_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)more));
+            EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, fn_multi, h->threads, more));
+            if (with == per_cu || h->blocks <= (int64_t)with * prop.multiProcessorCount) {
+                h->multi_dev_lds = (unsigned)at;
+                h->lds_step_multi = more;
+            }
+        }
     }
 #ifdef EC_STAMPS
     EC_TRY(dev_alloc(h, &d.stamps, (size_t)h->blocks * 16, true));
@@ -2688,6 +2739,21 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     if (h->rollout_mlp) {
         h->lds_rollout_mlp = ((h->lds_step + 15) & ~(size_t)15) + (polinl::H + 32) * sizeof(float);  // + layer-2/3 biases
         if (h->lds_rollout_mlp > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_rollout_mlp);
+        {   // + a copy of the geometry block, if that does not cost a resident block
+            int with = 0, without = 0;
+            const void* fn_mlp = reinterpret_cast<const void*>(h->rollout_mlp);
+            const size_t more = h->lds_rollout_mlp + sizeof(EcDev);
+            h->mlp_dev_lds = 0;
+            if (more <= 160 * 1024) {
+                EC_HIP(hipFuncSetAttribute(fn_mlp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)more));
+                EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&without, fn_mlp, h->threads, h->lds_rollout_mlp));
+                EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, fn_mlp, h->threads, more));
+                if (with == without || h->blocks <= (int64_t)with * prop.multiProcessorCount) {
+                    h->mlp_dev_lds = (unsigned)h->lds_rollout_mlp;
+                    h->lds_rollout_mlp = more;
+                }
+            }
+        }
         EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->rollout_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lds_rollout_mlp));
         EC_TRY(dev_alloc(h, &h->d_staged, (size_t)polinl::staged_floats(N)));
@@ -2772,9 +2838,11 @@ static int step_impl(ec_handle h, const int64_t* actions, float* reward, uint8_t
                      float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail, StepPolicy pol,
                      void* stream) {
     if (!h || !actions) return ec::fail(EC_EINVAL, "null handle or actions");
-    hipLaunchKernelGGL(pol.n_steps > 1 ? h->step_multi : h->step, dim3((unsigned)h->blocks), dim3(h->threads),
-                       h->lds_step, (hipStream_t)stream, h->d, h->d_dev, actions, reward, terminated, counters,
-                       completion_time, next_obs, next_avail, pol);
+    const bool multi = pol.n_steps > 1;
+    pol.dev_lds = multi ? h->multi_dev_lds : 0;
+    hipLaunchKernelGGL(multi ? h->step_multi : h->step, dim3((unsigned)h->blocks), dim3(h->threads),
+                       multi ? h->lds_step_multi : h->lds_step, (hipStream_t)stream, h->d, h->d_dev, actions, reward,
+                       terminated, counters, completion_time, next_obs, next_avail, pol);
     if (hop_hist) {
         const int64_t n = h->d.B * h->d.H;
         hipLaunchKernelGGL(k_copy_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -2827,7 +2895,7 @@ int ec_rollout_mlp_policy(ec_handle h, int32_t n_steps, const float* w1, const f
     if (rc != EC_OK) return rc;
     hipLaunchKernelGGL(h->rollout_mlp, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_rollout_mlp, (hipStream_t)stream,
                        h->d_dev, MlpRollout{h->d_staged, uniforms, obs0, avail0, n_steps,
-                                            (unsigned)((h->lds_step + 15) & ~(size_t)15)}, actions, reward, terminated,
+                                            (unsigned)((h->lds_step + 15) & ~(size_t)15), h->mlp_dev_lds}, actions, reward, terminated,
                        counters, completion_time, next_obs, next_avail);
     if (hop_hist) {
         const int64_t n = h->d.B * h->d.H;
