@@ -117,13 +117,17 @@ class ParallelRunner:
     def _episode(self, test_mode):
         args, env = self.args, self.env
         B, N = args.n_threads, args.n_agents
-        self.agent.buffer.reset()
+        fast = self._store.usable(self.agent.buffer)
+        kernel = fast and self._kernel_rollout_ok()
+        if kernel and not test_mode:
+            self.agent.buffer.t = 0  # ec_store_episode overwrites every element: no need to zero 540 MB first
+        else:
+            self.agent.buffer.reset()
         env.reset()
         env.observe()
         self._totals.zero_()
-        fast = self._store.usable(self.agent.buffer)
         buf = None if test_mode else self.agent.buffer
-        if fast and self._kernel_rollout_ok():
+        if kernel:
             return self._episode_kernel(test_mode)
         if fast and buf is not None:
             self._store.initial(buf)
