@@ -131,7 +131,9 @@ struct PpoArgs {
 };
 
 // HEAD 0: actor (TO3 output tiles), HEAD 1: critic.  IN1T: tiles of the first layer's dense input (9 + n_agents).
-template <int HEAD, int TO3, int IN1T>
+// BWD false: the forward-only passes (old log-probs, old values): the same forward arithmetic without the persistent
+// gradient accumulators, so that two blocks fit a CU instead of one.
+template <int HEAD, int TO3, int IN1T, bool BWD>
 __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
     extern __shared__ __align__(16) float lds[];
     const int nw = blockDim.x >> 6;
@@ -170,11 +172,11 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int jrow = lane & 31, half = lane >> 5;
     const int availw = HEAD == 0 ? 32 * A : 0;
-    float* s_obs = s_wave + (size_t)wave * (32 * OBS + 4 + availw + 2 * 64 * TS);
+    float* s_obs = s_wave + (size_t)wave * (32 * OBS + 4 + availw + (BWD ? 2 * 64 * TS : 0));
     int32_t* s_av = reinterpret_cast<int32_t*>(s_obs + 32 * OBS + 4);
     float* Td = s_obs + 32 * OBS + 4 + availw;
     float* Ta = Td + 64 * TS;
-    const bool backward = p.grads != nullptr;
+    constexpr bool backward = BWD;  // the launcher picks the instantiation by p.grads
 
     // persistent gradient accumulators of this wave
     f32x16 gW1[2][IN1T], gW2[2][2], gW3[T3][2];
@@ -425,29 +427,37 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
 
 constexpr size_t PPO_LDS_MAX = 160 * 1024;
 
-size_t ppo_lds_bytes(int head, int TO3, int N, int A, int nw) {
+size_t ppo_lds_bytes(int head, int TO3, int N, int A, int nw, bool bwd) {
     size_t f = 8 * 2 * 64 + 2 * (32 * 2 * 64);
     f += head == 0 ? (size_t)32 * TO3 * 64 + (size_t)16 * TO3 * 2 * 64 : 64;
     f += 2 * H + 32 * (head == 0 ? TO3 : 1) + (size_t)N * H;
-    const size_t per_wave = 32 * OBS + 4 + (head == 0 ? 32 * A : 0) + 2 * 64 * TS;
+    const size_t per_wave = 32 * OBS + 4 + (head == 0 ? 32 * A : 0) + (bwd ? 2 * 64 * TS : 0);  // transposition tiles
     return sizeof(float) * (f + nw * per_wave);
 }
 
 template <int HEAD, int TO3, int IN1T>
 int launch_ppo(const PpoArgs& a, hipStream_t stream) {
     int nw = 4;
-    size_t lds = ppo_lds_bytes(HEAD, TO3, a.n_agents, a.A, nw);
+    const bool bwd = a.grads != nullptr;
+    size_t lds = ppo_lds_bytes(HEAD, TO3, a.n_agents, a.A, nw, bwd);
     if (lds > PPO_LDS_MAX) {
         nw = 2;
-        lds = ppo_lds_bytes(HEAD, TO3, a.n_agents, a.A, nw);
+        lds = ppo_lds_bytes(HEAD, TO3, a.n_agents, a.A, nw, bwd);
     }
     if (lds > PPO_LDS_MAX) return ec::fail(EC_EINVAL, "ec_ppo: %d agents need %zu B of LDS", a.n_agents, lds);
-    EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ppo<HEAD, TO3, IN1T>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t tiles = (a.R + 31) / 32;
     int64_t blocks = (tiles + nw - 1) / nw;
-    if (blocks > 256) blocks = 256;  // one block per CU: the row loop amortises weight staging and the final atomics
-    hipLaunchKernelGGL((k_ppo<HEAD, TO3, IN1T>), dim3((unsigned)blocks), dim3(64 * nw), lds, stream, a);
+    if (a.grads) {
+        EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ppo<HEAD, TO3, IN1T, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (blocks > 256) blocks = 256;  // one block per CU: the row loop amortises weight staging and the final atomics
+        hipLaunchKernelGGL((k_ppo<HEAD, TO3, IN1T, true>), dim3((unsigned)blocks), dim3(64 * nw), lds, stream, a);
+    } else {
+        EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ppo<HEAD, TO3, IN1T, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (blocks > 512) blocks = 512;  // two blocks per CU: no transposition tiles in LDS, a third of the registers
+        hipLaunchKernelGGL((k_ppo<HEAD, TO3, IN1T, false>), dim3((unsigned)blocks), dim3(64 * nw), lds, stream, a);
+    }
     EC_HIP(hipGetLastError());
     return EC_OK;
 }
