@@ -267,6 +267,24 @@ int ec_store_episode(const float* obs0, const int32_t* avail0, const float* hist
                      int64_t* buf_actions, float* buf_rewards, float* buf_masks, float* buf_next_obs, double* totals,
                      double* partial, uint32_t* done, void* stream);
 
+/* ec_store_episode for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE: it is the same launch as ec_store_episode with
+ * the `partial` / `done` workspace taken from a static device array inside the library instead of from the caller.
+ * It calls no hipMalloc / hipFree or any allocating routine; the caller still owns every input and output.
+ *   limit: episode_limit <= EC_STORE_EPISODE_STATIC_MAX_T (EC_EINVAL beyond it; the array is 256 B + MAX_T * 48 B
+ *          = 197 KB per GPU the library runs on, held until the process ends)
+ *   Every call on one GPU shares that GPU's array (each GPU has its own copy, found once per device with
+ *   hipGetSymbolAddress on the first call there): calls that overlap on one GPU — two streams, two threads — race;
+ *   calls on one stream are ordered and safe.  The arrival counter is cleared on the stream before each launch.
+ *   Outputs are bit-identical to ec_store_episode's. */
+#define EC_STORE_EPISODE_STATIC_MAX_T 4096
+int ec_store_episode_static(const float* obs0, const int32_t* avail0, const float* hist_obs, const int32_t* hist_avail,
+                            const int64_t* hist_actions, const float* hist_reward, const uint8_t* hist_terminated,
+                            const int32_t* hist_counters, const float* hist_completion_time, int64_t n_envs,
+                            int32_t n_agents, int32_t obs_dim, int32_t n_actions, int64_t episode_limit, float* buf_obs,
+                            int32_t* buf_avail, int64_t* buf_actions, float* buf_rewards, float* buf_masks,
+                            float* buf_next_obs, double* totals, void* stream);
+
 /* --- fused PPO loss + gradients ----------------------------------------------------------------------------------
  * One launch per network does the forward pass, the loss and the whole backward pass of the (obs | one-hot agent id)
  * -> 64 -> 64 -> {n_actions, 1} MLP over `rows` = B*T*n_agents rows (row r is agent r % n_agents) and ACCUMULATES

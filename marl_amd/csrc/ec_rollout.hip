@@ -6,6 +6,8 @@
 // reward / completion time / task counters.  In torch these are ~20 launches of 4-5 us each around a 54 us step
 // kernel; here it is one.  The observation written as next_obs[t] is also obs[t+1] / avail[t+1] of the next step, so
 // the runner never copies the env's observation tensors.
+#include <mutex>
+
 #include "ec_common.h"
 
 namespace {
@@ -171,6 +173,34 @@ __global__ void __launch_bounds__(256) k_store_episode(EpisodeArgs a) {
 
 }  // namespace
 
+namespace {
+
+int store_episode_launch(const char* who, const float* obs0, const int32_t* avail0, const float* hist_obs,
+                         const int32_t* hist_avail, const int64_t* hist_actions, const float* hist_reward,
+                         const uint8_t* hist_terminated, const int32_t* hist_counters, const float* hist_completion_time,
+                         int64_t n_envs, int32_t n_agents, int32_t obs_dim, int32_t n_actions, int64_t episode_limit,
+                         float* buf_obs, int32_t* buf_avail, int64_t* buf_actions, float* buf_rewards, float* buf_masks,
+                         float* buf_next_obs, double* totals, double* partial, uint32_t* done, hipStream_t stream) {
+    if (!hist_reward || !hist_terminated || !hist_counters || !hist_completion_time)
+        return ec::fail(EC_EINVAL, "%s: null step history", who);
+    if (buf_obs && (!buf_avail || !buf_actions || !buf_rewards || !buf_masks || !buf_next_obs || !obs0 || !avail0 ||
+                    !hist_obs || !hist_avail || !hist_actions))
+        return ec::fail(EC_EINVAL, "%s: incomplete buffer or observation history", who);
+    if (totals && (!partial || !done)) return ec::fail(EC_EINVAL, "%s: totals need the partial / done scratch", who);
+    const int64_t copy_blocks = buf_obs ? n_envs * ((episode_limit + EP_TC - 1) / EP_TC) : 0;
+    const int64_t blocks = copy_blocks + (totals ? episode_limit : 0);
+    if (blocks == 0) return EC_OK;
+    if (blocks > 0x7fffffffll) return ec::fail(EC_EINVAL, "%s: %lld blocks", who, (long long)blocks);
+    EpisodeArgs a{obs0, avail0, hist_obs, hist_avail, hist_actions, hist_reward, hist_terminated, hist_counters,
+                  hist_completion_time, n_envs, n_agents, obs_dim, n_actions, episode_limit, buf_obs, buf_avail,
+                  buf_actions, buf_rewards, buf_masks, buf_next_obs, totals, partial, done, copy_blocks};
+    hipLaunchKernelGGL(k_store_episode, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+}  // namespace
+
 extern "C" int ec_store_episode(const float* obs0, const int32_t* avail0, const float* hist_obs, const int32_t* hist_avail,
                                 const int64_t* hist_actions, const float* hist_reward, const uint8_t* hist_terminated,
                                 const int32_t* hist_counters, const float* hist_completion_time, int64_t n_envs,
@@ -179,22 +209,69 @@ extern "C" int ec_store_episode(const float* obs0, const int32_t* avail0, const 
                                 float* buf_masks, float* buf_next_obs, double* totals, double* partial, uint32_t* done,
                                 void* stream) {
     if (n_envs <= 0 || episode_limit <= 0) return EC_OK;
-    if (!hist_reward || !hist_terminated || !hist_counters || !hist_completion_time)
-        return ec::fail(EC_EINVAL, "ec_store_episode: null step history");
-    if (buf_obs && (!buf_avail || !buf_actions || !buf_rewards || !buf_masks || !buf_next_obs || !obs0 || !avail0 ||
-                    !hist_obs || !hist_avail || !hist_actions))
-        return ec::fail(EC_EINVAL, "ec_store_episode: incomplete buffer or observation history");
-    if (totals && (!partial || !done)) return ec::fail(EC_EINVAL, "ec_store_episode: totals need the partial / done scratch");
-    const int64_t copy_blocks = buf_obs ? n_envs * ((episode_limit + EP_TC - 1) / EP_TC) : 0;
-    const int64_t blocks = copy_blocks + (totals ? episode_limit : 0);
-    if (blocks == 0) return EC_OK;
-    if (blocks > 0x7fffffffll) return ec::fail(EC_EINVAL, "ec_store_episode: %lld blocks", (long long)blocks);
-    EpisodeArgs a{obs0, avail0, hist_obs, hist_avail, hist_actions, hist_reward, hist_terminated, hist_counters,
-                  hist_completion_time, n_envs, n_agents, obs_dim, n_actions, episode_limit, buf_obs, buf_avail,
-                  buf_actions, buf_rewards, buf_masks, buf_next_obs, totals, partial, done, copy_blocks};
-    hipLaunchKernelGGL(k_store_episode, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-    EC_HIP(hipGetLastError());
+    return store_episode_launch("ec_store_episode", obs0, avail0, hist_obs, hist_avail, hist_actions, hist_reward,
+                                hist_terminated, hist_counters, hist_completion_time, n_envs, n_agents, obs_dim,
+                                n_actions, episode_limit, buf_obs, buf_avail, buf_actions, buf_rewards, buf_masks,
+                                buf_next_obs, totals, partial, done, (hipStream_t)stream);
+}
+
+// ---- ec_store_episode_static: the same launch for callers that cannot allocate ------------------------------------
+// The per-step partial sums and the arrival counter of k_store_episode live in a file-scope device array instead of a
+// caller-provided workspace.  Layout: bytes [0, 256) = the arrival counter `done` (first word; the rest of the line
+// is padding so that the counter has a 256-byte block to itself), then EC_STORE_EPISODE_STATIC_MAX_T rows of 6 f64
+// partial sums.  Every GPU the library runs on holds its own copy (197 KB) until the process ends.  In host code the
+// array's NAME is only a handle for hipGetSymbolAddress: its device address is looked up once per device and kept in
+// g_scratch_ptr; kernels, memsets and copies take that pointer, never the name.
+constexpr int64_t EP_STATIC_HEAD = 256;  // bytes in front of the partial sums
+static __device__ __align__(256) unsigned char scratch[EP_STATIC_HEAD + EC_STORE_EPISODE_STATIC_MAX_T * 6 * sizeof(double)];
+
+namespace {
+
+constexpr int EP_MAX_DEVICES = 64;
+void* g_scratch_ptr[EP_MAX_DEVICES] = {};  // per device: address of that GPU's copy of `scratch`
+std::mutex g_scratch_mutex;
+
+// the current device's copy of `scratch` (looked up on the first call on that device, with that device current)
+int scratch_of_current_device(unsigned char** out) {
+    int dev = -1;
+    EC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= EP_MAX_DEVICES)
+        return ec::fail(EC_EINVAL, "ec_store_episode_static: device %d outside [0, %d)", dev, EP_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        EC_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return ec::fail(EC_EHIP, "ec_store_episode_static: hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = p;
+    }
+    *out = (unsigned char*)g_scratch_ptr[dev];
     return EC_OK;
+}
+
+}  // namespace
+
+extern "C" int ec_store_episode_static(const float* obs0, const int32_t* avail0, const float* hist_obs,
+                                       const int32_t* hist_avail, const int64_t* hist_actions, const float* hist_reward,
+                                       const uint8_t* hist_terminated, const int32_t* hist_counters,
+                                       const float* hist_completion_time, int64_t n_envs, int32_t n_agents,
+                                       int32_t obs_dim, int32_t n_actions, int64_t episode_limit, float* buf_obs,
+                                       int32_t* buf_avail, int64_t* buf_actions, float* buf_rewards, float* buf_masks,
+                                       float* buf_next_obs, double* totals, void* stream) {
+    if (n_envs <= 0 || episode_limit <= 0) return EC_OK;
+    if (episode_limit > EC_STORE_EPISODE_STATIC_MAX_T)
+        return ec::fail(EC_EINVAL, "ec_store_episode_static: episode_limit %lld exceeds the static scratch's %d steps "
+                        "(use ec_store_episode with a caller-provided workspace)", (long long)episode_limit,
+                        (int)EC_STORE_EPISODE_STATIC_MAX_T);
+    unsigned char* base = nullptr;
+    if (int rc = scratch_of_current_device(&base)) return rc;
+    // the array keeps the last call's contents: the arrival counter must start at zero (k_store_episode leaves it at
+    // zero, but a launch that was aborted half-way would not), the partial sums are all rewritten before they are read
+    if (totals) EC_HIP(hipMemsetAsync(base, 0, EP_STATIC_HEAD, (hipStream_t)stream));
+    return store_episode_launch("ec_store_episode_static", obs0, avail0, hist_obs, hist_avail, hist_actions, hist_reward,
+                                hist_terminated, hist_counters, hist_completion_time, n_envs, n_agents, obs_dim,
+                                n_actions, episode_limit, buf_obs, buf_avail, buf_actions, buf_rewards, buf_masks,
+                                buf_next_obs, totals, (double*)(base + EP_STATIC_HEAD), (uint32_t*)base,
+                                (hipStream_t)stream);
 }
 
 extern "C" int ec_store_transition(const float* obs, const int32_t* avail, const int64_t* actions, const float* reward,
