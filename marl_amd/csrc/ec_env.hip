@@ -50,6 +50,8 @@ constexpr int RB_TASK = 4;   // doubles of the task stream staged per refill (bi
 constexpr int AHEAD_TASK = 2 * RB_TASK;
 constexpr int RB_EARLY = 16;  // draws of the window staged before the step's first barrier; the rest follows during the mini-slots
 constexpr u32 STAGED_FINAL = 0x80000000u;  // flag on the window's staged count: the producer will add no more
+constexpr u32 STAGED_COUNT = 0xffu;        // RC_STAGED word: bits 0-7 draws staged, bits 8-23 "hot" flags of the first
+constexpr int STAGED_HOT_SHIFT = 8;        // RB_EARLY draws (see StepLds::hot), bit 31 STAGED_FINAL
 constexpr int AHEAD_MAX = 512;  // cap of the words kept regenerated ahead (a 64-word batch must not lap the cursor)
 constexpr int ACC_LDS = 256; // low part of the tick LUT kept in LDS
 
@@ -118,6 +120,9 @@ struct alignas(16) EcDev {
     const double* acc;        // [maxTicks+1]
     const double* cap;        // [N]
     const u64* thr_exec_m;    // [N] floor(exp(-efr*dt) * 2^53)
+    const u32* hot_thr;       // [N] lowest 27-bit first-word threshold of the node's failure tests (execution and every
+                              //     in-link): a draw whose first word is below it fails no test (event skipping)
+    const u32* pad_ptr_;      // keeps sizeof(EcDev) a multiple of 16
     const double* qlen;       // [N]
     const double* qthr;       // [N] qlen * rl_queue_coeff
     const float* obs_const;   // [N][3]
@@ -180,6 +185,7 @@ __device__ __forceinline__ void ec_dev_globalize(EcDev& d, size_t zero) {
     EC_G(acc);
     EC_G(cap);
     EC_G(thr_exec_m);
+    EC_G(hot_thr);
     EC_G(qlen);
     EC_G(qthr);
     EC_G(obs_const);
@@ -496,6 +502,12 @@ struct RngFail {
         ahead -= 2 * idx;
         used += idx;
         stage(n);
+    }
+    // bit i set: window draw i (i < n <= 64) reaches the first-word threshold `thr` (read back from the window)
+    __device__ __forceinline__ u64 hot_mask(u32 n, u32 thr) const {
+        u64 m = 0;
+        for (u32 i = 0; i < n; i++) m |= (u64)(buf[i * stride] >= thr ? 1u : 0u) << i;
+        return m;
     }
     // second word of window draw i, as numpy's b = word >> 6
     __device__ __forceinline__ u32 b_of(u32 i) const { return mt_temper(mt[mt_wrap(pos + 2 * i + 1)]) >> 6; }
@@ -928,6 +940,8 @@ struct StepLds {
     u32* cnt;        // [4][NT]
     double* tu;      // [RB_TASK][NT] the step's task-stream doubles (producer -> consumer)
     u64* fullbits;   // [NT] (one word per env used) "queue full" flags of an env's nodes, for the fused observation
+    u64* hot;        // [NT] aliases fullbits (dead until phase E): bit i = draw i of the failure window is "hot", i.e.
+                     //      its first word reaches d.hot_thr[node] and may fail a test; all other draws fail none
     u32* rc;         // [RC_N][NT] RNG cursors and the producer/consumer hand-off (RC_*)
 };
 enum { RC_FPOS, RC_FAHEAD, RC_TPOS, RC_TAHEAD, RC_FDELTA, RC_TDELTA, RC_DONE, RC_NX, RC_STAGED, RC_N };
@@ -1029,6 +1043,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         S.ct = reinterpret_cast<double*>(p);     p += (size_t)NT * 8;
         S.tu = reinterpret_cast<double*>(p);     p += (size_t)NT * RB_TASK * 8;
         S.fullbits = reinterpret_cast<u64*>(p);  p += (size_t)NT * 8;
+        S.hot = S.fullbits;
         S.fa = reinterpret_cast<u32*>(p);        p += (size_t)NT * (RB_FAIL + 1) * 4;
         S.rqhs = reinterpret_cast<u32*>(p);      p += (size_t)NT * DMAX * 4;
         S.rqhead = reinterpret_cast<u32*>(p);    p += (size_t)NT * DMAX * 4;
@@ -1269,6 +1284,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         const u32 fpos = first ? d.rng_pos[fl] : S.rc[RC_FPOS * NT + ri], fah = first ? d.rng_ahead[fl] : S.rc[RC_FAHEAD * NT + ri];
         RngTask pt;
         RngFail pf;
+        const u32 hthr = d.hot_thr[R.node];
         if (tah >= (u32)AHEAD_TASK && fah >= (u32)AHEAD_FAIL) {
             // the common case: both streams are regenerated far enough; every load is issued before the first
             // word is tempered, so the whole window costs one memory round trip
@@ -1280,12 +1296,17 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
 #pragma unroll
             for (int i = 0; i < RB_EARLY / 2; i++) fv[i] = *reinterpret_cast<const u32x4*>(fw + 4 * i);
             const u32x4 t0 = *reinterpret_cast<const u32x4*>(tw), t1 = *reinterpret_cast<const u32x4*>(tw + 4);
+            u32 hot16 = 0;
 #pragma unroll
             for (int i = 0; i < RB_EARLY / 2; i++) {
-                S.fa[(2 * i) * NT + ri] = mt_temper(fv[i].x) >> 5;
-                S.fa[(2 * i + 1) * NT + ri] = mt_temper(fv[i].z) >> 5;
+                const u32 a0 = mt_temper(fv[i].x) >> 5, a1 = mt_temper(fv[i].z) >> 5;
+                S.fa[(2 * i) * NT + ri] = a0;
+                S.fa[(2 * i + 1) * NT + ri] = a1;
+                hot16 |= (a0 >= hthr ? 1u : 0u) << (2 * i);
+                hot16 |= (a1 >= hthr ? 1u : 0u) << (2 * i + 1);
             }
-            S.rc[RC_STAGED * NT + ri] = (u32)RB_EARLY;
+            static_assert(RB_EARLY <= 16, "the early hot flags share the RC_STAGED word");
+            S.rc[RC_STAGED * NT + ri] = (u32)RB_EARLY | (hot16 << STAGED_HOT_SHIFT);
             pt.u0 = mt_to_double(t0.x, t0.y);
             pt.u1 = mt_to_double(t0.z, t0.w);
             pt.u2 = mt_to_double(t1.x, t1.y);
@@ -1295,6 +1316,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         } else {
             pt.open(d.mt + tl * MT_STRIDE, tpos, tah);
             pf.open(d.mt + fl * MT_STRIDE, fpos, fah, S.fa + ri, NT, (u32)RB_FAIL);
+            S.hot[ri] = pf.hot_mask((u32)RB_FAIL, hthr);
             S.rc[RC_STAGED * NT + ri] = (u32)RB_FAIL | STAGED_FINAL;
         }
         S.tu[0 * NT + ri] = pt.u0;
@@ -1402,7 +1424,8 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
             for (int s = 0; s < rdeg; s++) n_ne += S.rqlen[s * NT + ri] > 0 ? 1u : 0u;
             const u32 nx = S.rc[RC_NX * NT + ri];
             const u32 bound = (u32)d.S * ((nx < (u32)d.k ? nx : (u32)d.k) + n_ne);  // the step's draw bound, as below
-            if (S.rc[RC_STAGED * NT + ri] < (u32)RB_FAIL) {
+            const u32 staged1 = S.rc[RC_STAGED * NT + ri];
+            if (!(staged1 & STAGED_FINAL)) {
                 // the rest of the window, as far as this step can draw (fah >= AHEAD_FAIL here)
                 const u32 upto = bound < (u32)RB_FAIL ? bound : (u32)RB_FAIL;
                 const u32* fw = d.mt + ((size_t)P + (size_t)R.lane) * MT_STRIDE + fpos;
@@ -1412,11 +1435,18 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                     fv[i] = u32x4{0, 0, 0, 0};
                     if ((u32)(RB_EARLY + 2 * i) < upto) fv[i] = *reinterpret_cast<const u32x4*>(fw + 4 * (i + RB_EARLY / 2));
                 }
+                const u32 hthr = d.hot_thr[R.node];
+                u64 hotm = (u64)((staged1 >> STAGED_HOT_SHIFT) & 0xffffu);
 #pragma unroll
                 for (int i = 0; i < (RB_FAIL - RB_EARLY) / 2; i++) {
-                    S.fa[(RB_EARLY + 2 * i) * NT + ri] = mt_temper(fv[i].x) >> 5;
-                    S.fa[(RB_EARLY + 2 * i + 1) * NT + ri] = mt_temper(fv[i].z) >> 5;
+                    const u32 a0 = mt_temper(fv[i].x) >> 5, a1 = mt_temper(fv[i].z) >> 5;
+                    S.fa[(RB_EARLY + 2 * i) * NT + ri] = a0;
+                    S.fa[(RB_EARLY + 2 * i + 1) * NT + ri] = a1;
+                    hotm |= (u64)(a0 >= hthr ? 1u : 0u) << (RB_EARLY + 2 * i);
+                    hotm |= (u64)(a1 >= hthr ? 1u : 0u) << (RB_EARLY + 2 * i + 1);
                 }
+                static_assert(RB_FAIL <= 64, "one hot bit per window draw");
+                S.hot[ri] = hotm;  // (draws beyond `staged` were not loaded: their bits are never looked at)
                 const u32 staged = upto < (u32)RB_EARLY ? (u32)RB_EARLY : (upto + 1u) & ~1u;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __hip_atomic_store(&S.rc[RC_STAGED * NT + ri], staged | STAGED_FINAL, __ATOMIC_RELAXED,
@@ -1441,6 +1471,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
     // Within a step no queue gains a task after phase A, so this bounds the lane's draws: per mini-slot at most
     // min(k, executing + waiting) execution draws and one draw per non-empty receiving queue.
     u32 draw_bound = 0;
+    u64 hot = 0;  // "hot" draws of the failure window (StepLds::hot); bits at or beyond frng.staged are undefined
     bool f_final = true;  // the producer has staged all it is going to stage of the first window
     if (L.valid) {
         u32 n_ne = 0;
@@ -1454,9 +1485,12 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         }
         const u32 n_ex = ex_n + wq_len < (u32)d.k ? ex_n + wq_len : (u32)d.k;
         draw_bound = (u32)d.S * (n_ex + n_ne);
+        const u32 st0 = S.rc[RC_STAGED * NT + tid];
         frng.attach(d.mt + ((size_t)P + lane) * MT_STRIDE, S.rc[RC_FPOS * NT + tid], S.rc[RC_FAHEAD * NT + tid],
-                    S.fa + tid, NT, S.rc[RC_STAGED * NT + tid] & ~STAGED_FINAL);
-        f_final = (S.rc[RC_STAGED * NT + tid] & STAGED_FINAL) != 0;
+                    S.fa + tid, NT, st0 & STAGED_COUNT);
+        f_final = (st0 & STAGED_FINAL) != 0;
+        // (a window the producer is still filling: the flags of its first RB_EARLY draws travel in the count word)
+        hot = f_final ? S.hot[tid] : (u64)((st0 >> STAGED_HOT_SHIFT) & 0xffffu);
     }
     bool f_synced = false;  // frng.ahead includes the producer's part-2 regeneration
 
@@ -1465,12 +1499,59 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
     double rew = 0.0, ct = 0.0;
     u32 n_fail = 0, n_drop = 0, n_fin = 0, n_succ = 0;
     if (L.valid) {
-#ifdef ABL_TICKS
-        for (int ms = 0; ms < ABL_TICKS; ms++) {
-#else
-        for (int ms = 0; ms < d.S; ms++) {
-#endif
-            const u32 c = c0 + (u32)ms;
+        // Event skipping.  Inside a step the nodes of an env do not interact (offload_task pushed everything in phase
+        // A), so a lane need not walk the mini-slots in lock step with its wave.  Most mini-slots of a lane are
+        // uneventful: every executing task and every non-empty receiving queue draws one number that fails nothing and
+        // one tick is added to the running timers.  Such mini-slots are taken in one jump (timers += n, draw cursor
+        // += n * draws per mini-slot); the reference's per-mini-slot code below runs only for mini-slots in which
+        // something can happen: an admission, a task reaching its finish tick, a head record arriving, a deadline
+        // sweep coming due, a draw whose first word reaches the node's lowest failure threshold ("hot"), or the end of
+        // the staged part of the draw window.  A wave iterates as often as its busiest lane has such mini-slots.
+        const u32 S_ = (u32)d.S;
+        u32 ms = 0;
+        for (;;) {
+            u32 m = ms;  // the next mini-slot that needs the full code
+            u32 q = ex_n;  // draws per uneventful mini-slot
+#pragma unroll
+            for (int s = 0; s < DMAX; s++) q += rql[s] > 0 ? 1u : 0u;
+            if (!(ex_n < (u32)d.k && wq_len > 0)) {  // else: an admission at once (edge_node.py:238-241)
+                const u32 cnow = c0 + ms;
+                m = S_;
+#pragma unroll
+                for (int s = 0; s < KMAX; s++) {  // a task completes or drops at the call that takes cet to fin
+                    const u32 cet = exw[s] & 0xffffu, fin = exw[s] >> 16;
+                    const u32 at = ms + (fin > cet + 1 ? fin - cet - 1 : 0u);
+                    m = ((u32)s < ex_n && at < m) ? at : m;
+                }
+#pragma unroll
+                for (int s = 0; s < DMAX; s++) {  // a head record arrives at call rqa
+                    const u32 at = rqa[s] > cnow ? rqa[s] - c0 : ms;
+                    m = (rql[s] > 0 && at < m) ? at : m;
+                }
+                {   // the deadline sweep of the waiting queue comes due at call wq_min
+                    const u32 at = wq_min > cnow ? wq_min - c0 : ms;
+                    m = (wq_len > 0 && at < m) ? at : m;
+                }
+                if (q > 0) {  // the first hot draw, or the end of what is staged of the window
+                    const u32 left = frng.staged - frng.idx;  // staged draws not yet consumed (<= RB_FAIL)
+                    const u64 h = (hot >> frng.idx) & ((1ull << left) - 1ull);
+                    const u32 pd = h ? (u32)__ffsll((unsigned long long)h) - 1u : left;
+                    // pd / q for pd <= 64, q <= KMAX + DMAX: (pd + 0.5) / q is at least 0.5 / q away from an integer
+                    const u32 at = ms + (u32)(((float)pd + 0.5f) * __builtin_amdgcn_rcpf((float)q));
+                    m = at < m ? at : m;
+                }
+                m = m < S_ ? m : S_;
+                const u32 jump = m - ms;
+#pragma unroll
+                for (int s = 0; s < KMAX; s++) {
+                    const u32 cet = (exw[s] & 0xffffu) + jump;
+                    exw[s] = (u32)s < ex_n ? ((exw[s] & 0xffff0000u) | (cet > 0xfffeu ? 0xfffeu : cet)) : exw[s];
+                }
+                frng.idx += jump * q;
+            }
+            if (m >= S_) break;
+            ms = m + 1;
+            const u32 c = c0 + m;
             // ---- execute_task, edge_node.py:236-309
             // (i) admit heads of the waiting queue while a slot is free (:238-241)
             while (ex_n < (u32)d.k && wq_len > 0) {
@@ -1510,7 +1591,8 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                          STAGED_FINAL))
                     __builtin_amdgcn_s_sleep(2);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                frng.staged = st & ~STAGED_FINAL;
+                frng.staged = st & STAGED_COUNT;
+                hot = S.hot[tid];
                 f_final = true;
             }
             if (frng.idx + ex_n + n_ne > frng.staged) {
@@ -1527,6 +1609,10 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
 #endif
                 const u32 left = draw_bound - (frng.used + frng.idx);  // the bound only shrinks as draws are spent
                 frng.restage(left < (u32)RB_FAIL ? left : (u32)RB_FAIL);
+                u32 hthr = exA_thr;
+#pragma unroll
+                for (int s = 0; s < DMAX; s++) hthr = lkA[s] < hthr ? lkA[s] : hthr;
+                hot = frng.hot_mask(frng.staged, hthr);
             }
             u32 ae[KMAX], ar[DMAX], ir[DMAX];
             const u32 base = frng.idx;
@@ -1747,10 +1833,6 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                     rqa[q] = s == q ? arr : rqa[q];
                 }
             }
-#ifdef EC_STAMPS
-            if (ms == 0 && threadIdx.x == 0 && d.stamps) d.stamps[(size_t)blockIdx.x * 16 + 9] = wall_clock64();
-            if (ms == 1 && threadIdx.x == 0 && d.stamps) d.stamps[(size_t)blockIdx.x * 16 + 10] = wall_clock64();
-#endif
         }
     }
 
@@ -2572,6 +2654,16 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     EC_TRY(dev_upload(h, &d.acc, acc));
     EC_TRY(dev_upload(h, &d.cap, cap));
     EC_TRY(dev_upload(h, &d.thr_exec_m, thr_exec_m));
+    {   // lowest first-word threshold (M >> 26) among a node's failure tests: below it a draw fails none of them
+        std::vector<u32> hot_thr(N);
+        for (int i = 0; i < N; i++) {
+            u64 lo = thr_exec_m[i];
+            for (int c = 0; c < deg[i]; c++) lo = thr_link_m[i * D + c] < lo ? thr_link_m[i * D + c] : lo;
+            hot_thr[i] = (u32)(lo >> 26);
+        }
+        EC_TRY(dev_upload(h, &d.hot_thr, hot_thr));
+        d.pad_ptr_ = nullptr;
+    }
     EC_TRY(dev_upload(h, &d.qlen, qlen));
     EC_TRY(dev_upload(h, &d.qthr, qthr));
     EC_TRY(dev_upload(h, &d.obs_const, obs_const));
