@@ -957,7 +957,10 @@ __host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int
     return b + 64;
 }
 
-constexpr u32 KIND_SUCCESS = 1u << 16;
+// executing slot in registers: exf = index of the execute_task call at which the task completes or drops (NEVER: the
+// slot is unused), exh = hop | EXH_SUCCESS | fin << 16 (fin: the current_execute_time, in ticks, at that call)
+constexpr u32 EXH_HOP = 0x7fffu;
+constexpr u32 EXH_SUCCESS = 1u << 15;
 
 // optional tail of the step: the uniform-random policy of ec_random_policy for the NEXT step, drawn from the
 // availability mask the fused observation has just produced (same generator, same row numbering)
@@ -986,7 +989,20 @@ __device__ __forceinline__ u64 policy_hash(u64 seed, u64 counter, u64 rows, u64 
     do {  /* the producer wave's timeline */                                                  \
         if ((int)threadIdx.x == d.nmain && d.stamps) d.stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); \
     } while (0)
+// time of wave 0 between consecutive EC_SUB points of the mini-slot loop, accumulated per point
+// (kept per wave in LDS by whichever lane is the first active one: lanes take different passes)
+#define EC_SUB(i)                                                                   \
+    do {                                                                            \
+        if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) {              \
+            const u64 now_ = wall_clock64();                                        \
+            dbg_lds[threadIdx.x >> 6][i] += now_ - dbg_lds[threadIdx.x >> 6][11];   \
+            dbg_lds[threadIdx.x >> 6][11] = now_;                                   \
+        }                                                                           \
+    } while (0)
 #else
+#define EC_SUB(i) \
+    do {          \
+    } while (0)
 #define EC_STAMP(i) \
     do {            \
     } while (0)
@@ -1009,7 +1025,7 @@ struct StepCarry {
     int64_t action;  // drawn by the previous step's policy tail
     double cap;
     u32 lkA[DMAX];
-    u32 exw[KMAX], exh[KMAX];
+    u32 exf[KMAX], exh[KMAX];
     double exT[KMAX];
     Rec newt;
     u32 buf_head, buf_len;
@@ -1096,14 +1112,14 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
     buf.head = buf.len = 0;
     buf.head_rec = newt;
     RngFail frng;
-    // executing slots: exw = cet | fin << 16 (fin: the cet at which the task drops or completes),
-    // exh = hop | KIND_SUCCESS, exT = the reference's task_time at cet == fin
-    u32 exw[KMAX], exh[KMAX];
+    // executing slots: exf / exh as described at EXH_HOP, exT = the reference's task_time at the finishing call
+    u32 exf[KMAX], exh[KMAX];
     double exT[KMAX];
     u32 rql[DMAX], rqa[DMAX];
 #pragma unroll
     for (int s = 0; s < KMAX; s++) {
-        exw[s] = exh[s] = 0;
+        exf[s] = NEVER;
+        exh[s] = 0;
         exT[s] = 0.0;
     }
 #pragma unroll
@@ -1136,7 +1152,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         for (int s = 0; s < DMAX; s++) lkA[s] = cr.lkA[s];
 #pragma unroll
         for (int s = 0; s < KMAX; s++) {
-            exw[s] = cr.exw[s];
+            exf[s] = cr.exf[s];
             exh[s] = cr.exh[s];
             exT[s] = cr.exT[s];
         }
@@ -1233,8 +1249,12 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
 #pragma unroll
         for (int s = 0; s < KMAX; s++) {
             if ((u32)s < ex_n) {
-                exw[s] = (u32)exa[s];
-                exh[s] = (u32)(exa[s] >> 32);
+                // memory form: cet | fin << 16 | hop << 32 | success << 48 (cet < fin: the next call is c0)
+                const u32 cet = (u32)exa[s] & 0xffffu, fin = ((u32)exa[s] >> 16) & 0xffffu;
+                const u32 hop = (u32)(exa[s] >> 32) & 0xffffu;
+                ovf |= hop > EXH_HOP ? 1u : 0u;
+                exf[s] = c0 + (fin > cet + 1 ? fin - cet - 1 : 0u);
+                exh[s] = (hop & EXH_HOP) | (((exa[s] >> 48) & 1ull) ? EXH_SUCCESS : 0u) | (fin << 16);
                 exT[s] = exb[s];
             }
         }
@@ -1509,29 +1529,62 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         // the staged part of the draw window.  A wave iterates as often as its busiest lane has such mini-slots.
         const u32 S_ = (u32)d.S;
         u32 ms = 0;
+#ifdef EC_STAMPS
+        u32 dbg_iters = 0;
+        __shared__ u64 dbg_lds[4][12];
+        if ((threadIdx.x & 63u) == 0) {
+            for (int i = 0; i < 11; i++) dbg_lds[threadIdx.x >> 6][i] = 0;
+            dbg_lds[threadIdx.x >> 6][11] = wall_clock64();
+        }
+#endif
         for (;;) {
-            u32 m = ms;  // the next mini-slot that needs the full code
+            // ---- execute_task (i), edge_node.py:238-241: the call with index c0 + ms admits heads of the waiting
+            // queue while a slot is free.  Done here, ahead of the search, so that a mini-slot whose only event is an
+            // admission (the call after a slot was vacated) needs no pass of its own.
+            if (ms < S_) {
+                const u32 c = c0 + ms;
+                while (ex_n < (u32)d.k && wq_len > 0) {
+                    const WMeta w = wmeta_unpack(S.wqm[wq_h * NT + tid]);
+                    wq_h = (wq_h + 1) & wmask;
+                    wq_len--;
+                    wq_dirty = true;
+                    const u32 ewt = sat16(c - w.enq, ovf);
+                    double Td;
+                    const u32 dc = lut.deadline_ticks(1, ewt, w.twt, w.ctt, w.bwt, &Td);
+                    // the drop test precedes the completion test (:268,278): a tie is a drop
+                    const bool succ = w.nexec < dc;
+                    const u32 fin = succ ? w.nexec : dc;
+                    const double T = succ ? lut.task_time(ewt, fin, w.twt, w.ctt, w.bwt) : Td;
+                    ovf |= w.hop > EXH_HOP ? 1u : 0u;
+                    const u32 nf = c + fin - 1, nh = (w.hop & EXH_HOP) | (succ ? EXH_SUCCESS : 0u) | (fin << 16);
+#pragma unroll
+                    for (int s = 0; s < KMAX; s++) {
+                        if ((u32)s == ex_n) {
+                            exf[s] = nf;
+                            exh[s] = nh;
+                            exT[s] = T;
+                        }
+                    }
+                    S.exC[ex_n * NT + tid] = pack4(ewt, w.twt, w.ctt, w.bwt);
+                    ex_n++;
+                }
+            }
+            EC_SUB(1);
+            // ---- the next mini-slot m >= ms that needs the full code
             u32 q = ex_n;  // draws per uneventful mini-slot
 #pragma unroll
             for (int s = 0; s < DMAX; s++) q += rql[s] > 0 ? 1u : 0u;
-            if (!(ex_n < (u32)d.k && wq_len > 0)) {  // else: an admission at once (edge_node.py:238-241)
+            u32 m;
+            {
+                // absolute call indices: a task completes or drops at exf (NEVER: slot unused), a head record arrives
+                // at rqa (NEVER: queue empty), the deadline sweep of the waiting queue comes due at wq_min
+                u32 na = wq_len > 0 ? wq_min : NEVER;
+#pragma unroll
+                for (int s = 0; s < KMAX; s++) na = exf[s] < na ? exf[s] : na;
+#pragma unroll
+                for (int s = 0; s < DMAX; s++) na = rqa[s] < na ? rqa[s] : na;
                 const u32 cnow = c0 + ms;
-                m = S_;
-#pragma unroll
-                for (int s = 0; s < KMAX; s++) {  // a task completes or drops at the call that takes cet to fin
-                    const u32 cet = exw[s] & 0xffffu, fin = exw[s] >> 16;
-                    const u32 at = ms + (fin > cet + 1 ? fin - cet - 1 : 0u);
-                    m = ((u32)s < ex_n && at < m) ? at : m;
-                }
-#pragma unroll
-                for (int s = 0; s < DMAX; s++) {  // a head record arrives at call rqa
-                    const u32 at = rqa[s] > cnow ? rqa[s] - c0 : ms;
-                    m = (rql[s] > 0 && at < m) ? at : m;
-                }
-                {   // the deadline sweep of the waiting queue comes due at call wq_min
-                    const u32 at = wq_min > cnow ? wq_min - c0 : ms;
-                    m = (wq_len > 0 && at < m) ? at : m;
-                }
+                m = na > cnow ? na - c0 : ms;
                 if (q > 0) {  // the first hot draw, or the end of what is staged of the window
                     const u32 left = frng.staged - frng.idx;  // staged draws not yet consumed (<= RB_FAIL)
                     const u64 h = (hot >> frng.idx) & ((1ull << left) - 1ull);
@@ -1541,50 +1594,20 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                     m = at < m ? at : m;
                 }
                 m = m < S_ ? m : S_;
-                const u32 jump = m - ms;
-#pragma unroll
-                for (int s = 0; s < KMAX; s++) {
-                    const u32 cet = (exw[s] & 0xffffu) + jump;
-                    exw[s] = (u32)s < ex_n ? ((exw[s] & 0xffff0000u) | (cet > 0xfffeu ? 0xfffeu : cet)) : exw[s];
-                }
-                frng.idx += jump * q;
+                frng.idx += (m - ms) * q;
             }
             if (m >= S_) break;
             ms = m + 1;
             const u32 c = c0 + m;
-            // ---- execute_task, edge_node.py:236-309
-            // (i) admit heads of the waiting queue while a slot is free (:238-241)
-            while (ex_n < (u32)d.k && wq_len > 0) {
-                const WMeta w = wmeta_unpack(S.wqm[wq_h * NT + tid]);
-                wq_h = (wq_h + 1) & wmask;
-                wq_len--;
-                wq_dirty = true;
-                const u32 ewt = sat16(c - w.enq, ovf);
-                double Td;
-                const u32 dc = lut.deadline_ticks(1, ewt, w.twt, w.ctt, w.bwt, &Td);
-                // the drop test precedes the completion test (:268,278): a tie is a drop
-                const bool succ = w.nexec < dc;
-                const u32 fin = succ ? w.nexec : dc;
-                const double T = succ ? lut.task_time(ewt, fin, w.twt, w.ctt, w.bwt) : Td;
-                const u32 nw = fin << 16, nh = w.hop | (succ ? KIND_SUCCESS : 0u);
-#pragma unroll
-                for (int s = 0; s < KMAX; s++) {
-                    if ((u32)s == ex_n) {
-                        exw[s] = nw;
-                        exh[s] = nh;
-                        exT[s] = T;
-                    }
-                }
-                S.exC[ex_n * NT + tid] = pack4(ewt, w.twt, w.ctt, w.bwt);
-                ex_n++;
-            }
+#ifdef EC_STAMPS
+            dbg_iters++;  // wave 0's count lands in stamp 9 of one-step launches (lanes differ: lane 0's is stored)
+#endif
+            EC_SUB(0);
             if (wq_len == 0) wq_min = NEVER;
+            EC_SUB(1);
 
-            // the draws of this mini-slot: one per executing task, then one per non-empty receiving queue
-            u32 n_ne = 0;
-#pragma unroll
-            for (int s = 0; s < DMAX; s++) n_ne += rql[s] > 0 ? 1u : 0u;
-            if (frng.idx + ex_n + n_ne > frng.staged && !f_final) {
+            // the draws of this mini-slot: one per executing task, then one per non-empty receiving queue (q in all)
+            if (frng.idx + q > frng.staged && !f_final) {
                 // the producer is still filling this window: it has been at it since the second barrier
                 u32 st;
                 while (!((st = __hip_atomic_load(&S.rc[RC_STAGED * NT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) &
@@ -1595,7 +1618,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                 hot = S.hot[tid];
                 f_final = true;
             }
-            if (frng.idx + ex_n + n_ne > frng.staged) {
+            if (frng.idx + q > frng.staged) {
                 if (!f_synced) {
                     // the producer may still be regenerating this stream: wait for it (it never waits for us)
                     while (__hip_atomic_load(&S.rc[RC_DONE * NT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
@@ -1632,6 +1655,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                 frng.idx = r;
             }
 
+            EC_SUB(2);
             // (ii) is implicit: waiting time is c - enq.  (iii) the executing tasks, in order (:252-296)
             // Integer bookkeeping in straight-line code for all slots.  EVX (the looping kernel): the fp64 reward /
             // completion-time terms and the hop histogram of the slots that failed or finished are added afterwards,
@@ -1644,20 +1668,18 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
 #pragma unroll
                 for (int s = 0; s < KMAX; s++) {
                     const bool act = (u32)s < n0;
-                    const u32 cet = (exw[s] & 0xffffu) + 1;
-                    const u32 fin = exw[s] >> 16;
                     bool fail = act && ae[s] > exA_thr;
                     if (act && ae[s] == exA_thr)  // 2^-27 tie on the first word
                         fail = frng.b_of(base + s) > (u32)(d.thr_exec_m[node] & 0x3ffffffull);
-                    const bool done = act && !fail && cet >= fin;
-                    const bool succ = done && (exh[s] & KIND_SUCCESS);
+                    const bool done = act && !fail && c >= exf[s];
+                    const bool succ = done && (exh[s] & EXH_SUCCESS);
                     const bool drop = done && !succ;
                     n_fail += fail;
                     n_drop += drop;
                     n_succ += succ;
                     n_fin += (fail || done);
                     if (!EVX) {
-                        const u32 hop = exh[s] & 0xffffu;
+                        const u32 hop = exh[s] & EXH_HOP;
                         rew = fail ? dadd(rew, d.pen_fail) : rew;
                         rew = drop ? dadd(rew, d.pen_drop) : rew;
                         rew = succ ? dadd(rew, d.rew_succ) : rew;
@@ -1676,9 +1698,9 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                     fbx |= fail ? (1u << s) : 0u;
                     sbx |= succ ? (1u << s) : 0u;
                     const bool kp = act && !fail && !done;
-                    exw[s] = kp ? ((exw[s] & 0xffff0000u) | (cet > 0xfffeu ? 0xfffeu : cet)) : exw[s];
                     keep |= kp ? (1u << s) : 0u;
                 }
+                EC_SUB(3);
                 while (EVX && evx) {
                     const int s = __ffs((int)evx) - 1;
                     evx &= evx - 1;
@@ -1694,7 +1716,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                         eT = s == q ? exT[q] : eT;
                     }
                     if ((sbx >> s) & 1u) {
-                        const u32 hop = eh & 0xffffu;
+                        const u32 hop = eh & EXH_HOP;
                         rew = dadd(rew, d.rew_succ);
                         rew = dadd(rew, hop > 1 ? dmul(d.pen_hop, (double)(hop - 1)) : 0.0);
                         u32 bin = hop;
@@ -1708,13 +1730,14 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                     }
                     ct = dadd(ct, eT);
                 }
+                EC_SUB(4);
                 if (keep != ((1u << n0) - 1)) {
                     // stable compaction of the survivors (executing_queue.remove keeps the order)
                     u32 nw[KMAX], nh[KMAX];
                     double nT[KMAX];
 #pragma unroll
                     for (int w = 0; w < KMAX; w++) {
-                        nw[w] = 0;
+                        nw[w] = NEVER;
                         nh[w] = 0;
                         nT[w] = 0.0;
                     }
@@ -1725,7 +1748,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
 #pragma unroll
                         for (int w = 0; w <= s; w++) {
                             const bool hit = kp && cnt == (u32)w;
-                            nw[w] = hit ? exw[s] : nw[w];
+                            nw[w] = hit ? exf[s] : nw[w];
                             nh[w] = hit ? exh[s] : nh[w];
                             nT[w] = hit ? exT[s] : nT[w];
                         }
@@ -1734,13 +1757,14 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                     }
 #pragma unroll
                     for (int w = 0; w < KMAX; w++) {
-                        exw[w] = nw[w];
+                        exf[w] = nw[w];
                         exh[w] = nh[w];
                         exT[w] = nT[w];
                     }
                     ex_n = cnt;
                 }
             }
+            EC_SUB(5);
             // (iv) deadline sweep of the waiting queue (:299-309), only when some drop has come due
             if (wq_len > 0 && wq_min <= c) {
                 u32 rd = wq_h, wr = wq_h, kept = 0, newmin = NEVER;
@@ -1768,6 +1792,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                 wq_min = newmin;
                 wq_dirty = true;
             }
+            EC_SUB(6);
             // ---- receive_task, edge_node.py:311-333: in-neighbours in ascending source order
             // Classify the queues in straight-line code, then handle the events (a failed or arrived head) one per
             // lane per pass, lowest slot first: the passes a wave makes are the most events any of its lanes has
@@ -1783,6 +1808,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                 ev |= (failed || arrived) ? (1u << s) : 0u;
                 fb |= failed ? (1u << s) : 0u;
             }
+            EC_SUB(7);
             while (ev) {
                 const int s = __ffs((int)ev) - 1;
                 ev &= ev - 1;
@@ -1833,7 +1859,23 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                     rqa[q] = s == q ? arr : rqa[q];
                 }
             }
+            EC_SUB(8);
         }
+#ifdef EC_STAMPS
+        {   // passes the wave made through the per-mini-slot code = the most any of its lanes needed
+            u32 w = dbg_iters;
+            for (int o = 32; o >= 1; o >>= 1) {
+                const u32 x = __shfl_xor(w, o);
+                w = x > w ? x : w;
+            }
+            if (threadIdx.x == 0 && d.stamps && first && last) {
+                d.stamps[(size_t)blockIdx.x * 16 + 9] = w;
+                d.stamps[(size_t)blockIdx.x * 16 + 10] = dbg_iters;
+                EC_SUB(9);
+                for (int i = 0; i < 10; i++) d.stamps[((size_t)gridDim.x + blockIdx.x) * 16 + i] = dbg_lds[0][i];
+            }
+        }
+#endif
     }
 
     EC_STAMP(4);
@@ -1917,7 +1959,10 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
 #pragma unroll
             for (int s = 0; s < KMAX; s++) {
                 if ((u32)s < ex_n) {
-                    d.exA[(size_t)s * P + lane] = (u64)exw[s] | ((u64)exh[s] << 32);
+                    // cet as the next step's first call (index c0 + S) will find it
+                    const u32 fin = exh[s] >> 16, cet = c0 + (u32)d.S + fin - 1 - exf[s];
+                    d.exA[(size_t)s * P + lane] = (u64)(cet & 0xffffu) | ((u64)fin << 16) | ((u64)(exh[s] & EXH_HOP) << 32) |
+                                                  ((exh[s] & EXH_SUCCESS) ? 1ull << 48 : 0ull);
                     d.exB[(size_t)s * P + lane] = exT[s];
                     d.exC[(size_t)s * P + lane] = S.exC[s * NT + tid];
                 }
@@ -1965,7 +2010,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
             }
 #pragma unroll
             for (int s = 0; s < KMAX; s++) {
-                cr.exw[s] = exw[s];
+                cr.exf[s] = exf[s];
                 cr.exh[s] = exh[s];
                 cr.exT[s] = exT[s];
             }
@@ -2822,7 +2867,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
         }
     }
 #ifdef EC_STAMPS
-    EC_TRY(dev_alloc(h, &d.stamps, (size_t)h->blocks * 16, true));
+    EC_TRY(dev_alloc(h, &d.stamps, (size_t)h->blocks * 32, true));  // [0, 16 blocks): phases; then the EC_SUB sums
 #endif
 
     EC_TRY(dev_alloc(h, &h->d_dev, 1));
@@ -3087,7 +3132,7 @@ int ec_info(ec_handle h, int64_t* info_host, int32_t n) {
 /* diagnostic build only: copy the per-block phase stamps of the last ec_step to the host */
 int ec_debug_stamps(ec_handle h, uint64_t* out_host, int64_t* n_blocks) {
     EC_HIP(hipDeviceSynchronize());
-    EC_HIP(hipMemcpy(out_host, h->d.stamps, sizeof(u64) * 16 * (size_t)h->blocks, hipMemcpyDeviceToHost));
+    EC_HIP(hipMemcpy(out_host, h->d.stamps, sizeof(u64) * 32 * (size_t)h->blocks, hipMemcpyDeviceToHost));
     *n_blocks = h->blocks;
     return EC_OK;
 }
