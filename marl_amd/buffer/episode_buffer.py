@@ -17,6 +17,11 @@ class EpisodeBuffer:
         self.masks = th.zeros(B, T, N, 1, dtype=th.float, **kw)
         self.next_obs = th.zeros(B, T, N, args.obs_shape, dtype=th.float, **kw)
         self.t = 0
+        # Set by the runners' transition store when it has filed a whole episode from reset: next_obs[:, t] is then
+        # obs[:, t+1] bit for bit and masks.sum() is known on the host, which lets the learners skip a 147 MB
+        # comparison, one critic pass and a device->host sync per iteration.  Any other writer clears them.
+        self.next_obs_is_shifted_obs = False
+        self.known_mask_sum = None
 
     def insert(self, obs, avail_actions, actions, rewards, masks, next_obs):
         t = self.t
@@ -27,6 +32,8 @@ class EpisodeBuffer:
         self.masks[:, t].copy_(masks, non_blocking=True)
         self.next_obs[:, t].copy_(next_obs, non_blocking=True)
         self.t += 1
+        self.next_obs_is_shifted_obs = False
+        self.known_mask_sum = None
 
     def sample(self):
         return self.obs, self.avail_actions, self.actions, self.rewards, self.masks, self.next_obs
@@ -35,6 +42,8 @@ class EpisodeBuffer:
         for t in (self.obs, self.avail_actions, self.actions, self.rewards, self.masks, self.next_obs):
             t.zero_()
         self.t = 0
+        self.next_obs_is_shifted_obs = False
+        self.known_mask_sum = None
 
     def can_sample(self) -> bool:
         return self.t >= self.args.episode_limit

@@ -7,6 +7,8 @@ host round trip (rows that are not selected are scattered to a spare slot past t
 """
 import torch as th
 
+from marl_amd.utils.random_source import RandomSource
+
 
 class ExpertTransitions:
     def __init__(self, capacity, n_agents, obs_shape, device):
@@ -15,6 +17,7 @@ class ExpertTransitions:
         self.obs = th.zeros(self.capacity + 1, n_agents, obs_shape, dtype=th.float32, device=self.device)
         self.actions = th.zeros(self.capacity + 1, n_agents, dtype=th.int64, device=self.device)
         self._written = th.zeros((), dtype=th.int64, device=self.device)  # transitions ever appended
+        self.rng = RandomSource(self.device)  # the learners share it (tests replace it to replay recorded draws)
 
     def __len__(self):
         """len(self.expert_transitions) of the reference (synchronises)."""
@@ -25,31 +28,32 @@ class ExpertTransitions:
         B = obs.shape[0]
         if select is None:
             select = th.ones(B, dtype=th.bool, device=self.device)
-        rank = th.cumsum(select.to(th.int64), 0) - 1
-        slot = th.where(select, (self._written + rank) % self.capacity, th.full_like(rank, self.capacity))
+        sel = select.to(th.int64)
+        rank = th.cumsum(sel, 0) - 1
+        n_sel = sel.sum()
+        # One call can select more rows than the ring holds (B > max_expert_buffer_size): the FIFO then keeps the
+        # newest `capacity` of them, as appending them one by one would.  Older selected rows go to the spare slot
+        # with the unselected ones, so every ring slot has exactly one source row and (obs, action) stay paired.
+        keep = select & (rank >= n_sel - self.capacity)
+        slot = th.where(keep, (self._written + rank) % self.capacity, th.full_like(rank, self.capacity))
         self.obs.index_copy_(0, slot, obs.to(self.device, th.float32))
         self.actions.index_copy_(0, slot, actions.to(self.device, th.int64))
-        self._written += select.sum()
+        self._written += n_sel
 
-    def sample_transitions(self, n, generator=None):
+    def sample_transitions(self, n):
         """n distinct transitions, uniformly (np.random.choice(len, n, replace=False) of the reference):
         returns obs [n,N,O], actions [n,N]."""
         size = len(self)
         n = min(int(n), size)
-        if n * 4 <= size:
-            # a uniformly random n-subset in random order = the n largest of `size` i.i.d. keys: two small kernels
-            # instead of the sort behind randperm (a dozen launches, once per minibatch step of the learners)
-            idx = th.rand(size, device=self.device, generator=generator).topk(n).indices
-        else:
-            idx = th.randperm(size, device=self.device, generator=generator)[:n]
+        idx = self.rng.choice_without_replacement(size, n)
         return self.obs[idx], self.actions[idx]
 
-    def sample_rows(self, n, generator=None):
+    def sample_rows(self, n):
         """n agent-rows with replacement over the concatenation of all stored transitions
         (dgail_agent.py:209-216): returns obs [n,O], actions [n]."""
         size = len(self)
         N = self.obs.shape[1]
-        idx = th.randint(0, size * N, (int(n),), device=self.device, generator=generator)
+        idx = self.rng.choice_with_replacement(size * N, int(n))
         return self.obs[:size].reshape(size * N, -1)[idx], self.actions[:size].reshape(-1)[idx]
 
     def state_dict(self):

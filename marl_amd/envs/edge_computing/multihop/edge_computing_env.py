@@ -306,6 +306,37 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
     def get_edges(self):
         return np.array(self.tables.unique_edges())
 
+    def get_obs_llm(self, env=0):
+        """EdgeComputingEnv.get_obs_llm (edge_computing_env.py:43-48) for one env of the batch: per node the dict of
+        EdgeNode.get_observation_llm (edge_node.py:138-157).  Host-side and synchronous (it serialises the env through
+        ec_debug_dump): this is the LLM-prompt path of step_runner / optimal_runner, not the rollout."""
+        self.check_status()
+        rows = self.debug_dump(env)
+        t, a = self.tables, self.args
+        out = []
+        for i in range(self.n_agents):
+            mine = rows[rows[:, 0] == i]
+            waiting = mine[mine[:, 1] == 2]
+            waiting = waiting[np.argsort(waiting[:, 2])]
+            w = 0.0
+            for et in waiting[:, 3]:  # get_waiting_time (edge_node.py:99-104): execute_time - 0, queue order
+                w += float(et)
+            new = mine[mine[:, 1] == 0]
+            rates = [float(v) for v in t.rate[i]]
+            o = {"node_id": i, "cpu_capacity": int(t.cores[i]),
+                 "cpu_utilization": round(len(waiting) / float(t.qlen_max[i]), 4),
+                 "execution_failure_rate": round(float(t.efr[i]), 4), "waiting_time": round(w, 4)}
+            if len(new):
+                o["task_size"] = float(new[0, 3]) / (1024 * 8)
+                o["task_cpu_cycle"] = float(new[0, 4]) / (a.task_size_max * 1024 * 8)
+            else:
+                o["task_size"] = 0
+                o["task_cpu_cycle"] = 0
+            o["transmission_rate"] = [round(v / max(rates), 4) for v in rates]
+            o["actions_space"] = list(t.neighbours[i]) + [i]
+            out.append(o)
+        return out
+
     def get_env_info(self):
         return {"state_shape": self.state_shape, "obs_shape": self.obs_shape, "n_actions": self.n_actions,
                 "n_agents": self.n_agents, "episode_limit": self.episode_limit}

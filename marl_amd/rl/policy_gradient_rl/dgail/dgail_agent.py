@@ -65,6 +65,7 @@ class DGAILAgent:
         self.expert_transitions = ExpertTransitions(args.max_expert_buffer_size, self.n_agents, self.obs_shape,
                                                     self.device)
         self.max_expert_buffer_size = args.max_expert_buffer_size
+        self.rng = self.expert_transitions.rng  # every random draw of the updates (utils/random_source.py)
 
         self.update_count = 0
         self.training_stats = {}
@@ -146,8 +147,8 @@ class DGAILAgent:
 
     def _d_phi(self, sa):
         ones = th.ones(sa.size(0), dtype=th.long, device=self.device)
-        lp = self.discriminator.compute_loss(sa, ones)
-        ln = self.discriminator.compute_loss(sa, th.zeros_like(ones))
+        lp = self.discriminator.compute_loss(sa, ones, *self.rng.diffusion_draws(sa.size(0), sa.size(1)))
+        ln = self.discriminator.compute_loss(sa, th.zeros_like(ones), *self.rng.diffusion_draws(sa.size(0), sa.size(1)))
         return th.exp(-lp) / (th.exp(-lp) + th.exp(-ln) + 1e-8)
 
     def _update_discriminator(self, agent_sa):
@@ -208,14 +209,22 @@ class DGAILAgent:
         else:
             rows = obs_flat.shape[0]
             d = self.discriminator
-            # the (t, noise) draws of the two compute_loss calls (dgail_network.py:90-91)
-            t_e = th.randint(0, 2, (rows,), device=self.device, dtype=th.uint8)
-            t_a = th.randint(0, 2, (rows,), device=self.device, dtype=th.uint8)
-            n_e = th.randn(rows, self.state_action_dim, device=self.device)
-            n_a = th.randn(rows, self.state_action_dim, device=self.device)
-            _, _, _, base = mlp_device.diffusion_reward(mlp_device.linear_params(d.mlp), d.time_embed.weight,
-                                                        d.cond_embed.weight, obs_flat, act_flat, self.n_actions, t_e,
-                                                        n_e, t_a, n_a, r1_lambda=d.R1_LAMBDA)
+            # the (t, noise) draws of the two compute_loss calls (dgail_network.py:90-91), expert condition first
+            t_e, n_e = self.rng.diffusion_draws(rows, self.state_action_dim)
+            t_a, n_a = self.rng.diffusion_draws(rows, self.state_action_dim)
+            t_e, t_a = t_e.to(th.uint8), t_a.to(th.uint8)
+            # The reference never puts the module in eval mode, so each compute_loss call runs one spectral-norm power
+            # iteration of its own: the expert loss sees W / sigma after the first iteration, the agent loss after the
+            # second (reading the parametrised weights performs the iteration).  One kernel pass per condition, each
+            # with the weights its call would see.
+            l_e, _, _, _ = mlp_device.diffusion_reward(mlp_device.linear_params(d.mlp), d.time_embed.weight,
+                                                       d.cond_embed.weight, obs_flat, act_flat, self.n_actions, t_e,
+                                                       n_e, t_a, n_a, r1_lambda=d.R1_LAMBDA)
+            _, l_a, _, _ = mlp_device.diffusion_reward(mlp_device.linear_params(d.mlp), d.time_embed.weight,
+                                                       d.cond_embed.weight, obs_flat, act_flat, self.n_actions, t_e,
+                                                       n_e, t_a, n_a, r1_lambda=d.R1_LAMBDA)
+            pe, pa = th.exp(-l_e), th.exp(-l_a)
+            base = -th.log(1.0 - pe / (pe + pa + 1e-8) + 1e-8)  # dgail_agent.py:497-499
             final = base * weight + 0.02 * env_flat
         return final.reshape(obs.shape[0], obs.shape[1], obs.shape[2], 1)
 
@@ -271,7 +280,7 @@ class DGAILAgent:
             if (self._graph_update and rows >= mb) else None
         totals = graph["totals"] if graph is not None else th.zeros(3, device=self.device)
         for _ in range(a.ppo_epochs):
-            perm = th.randperm(rows, device=self.device)
+            perm = self.rng.permutation(rows)
             for i in range(n_mb):
                 idx = perm[i * mb:(i + 1) * mb]
                 bc = self.expert_transitions.sample_transitions(a.batch_expert_transitions)

@@ -45,6 +45,7 @@ class GAILAgent:
         self.expert_transitions = ExpertTransitions(args.max_expert_buffer_size, args.n_agents, args.obs_shape,
                                                     self.device)
         self.max_expert_buffer_size = args.max_expert_buffer_size
+        self.rng = self.expert_transitions.rng  # every random draw of the updates (utils/random_source.py)
         self.update_count = 0
         self.performance_history = []
         self._eye = th.eye(args.n_agents, device=self.device)

@@ -100,9 +100,10 @@ class PPOAgent:
             rewards = (rewards - mean) / (std + 1e-5)
         old_logp, _ = ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, want_logp=True)
         old_v = ppo_device.critic_pass(self.critic, obs, masks, N, want_values=True).view(shape)
-        if shape[1] > 1 and th.equal(next_obs[:, :-1], obs[:, 1:]):
-            # the runner stores one observation as next_obs[t] and obs[t+1]: V(next_obs[t]) is V(obs[t+1]) (the kernel
-            # evaluates rows independently, so the values are the same bits); only the last step needs a pass
+        if shape[1] > 1 and getattr(self.buffer, "next_obs_is_shifted_obs", False):
+            # the runner's transition store filed one observation as next_obs[t] and obs[t+1] (it says so on the
+            # buffer): V(next_obs[t]) is V(obs[t+1]) (the kernel evaluates rows independently, so the values are the
+            # same bits); only the last step needs a pass
             last = ppo_device.critic_pass(self.critic, next_obs[:, -1:].contiguous(), masks[:, -1:].contiguous(), N,
                                           want_values=True).view(shape[0], 1, *shape[2:])
             old_next_v = th.cat([old_v[:, 1:], last], dim=1)
@@ -113,7 +114,11 @@ class PPOAgent:
             mean, std = global_mean_std(advantages)
             advantages = (advantages - mean) / (std + 1e-5)
         targets = advantages + old_v
-        inv_denom = 1.0 / float(all_reduce_sum_(masks.sum().reshape(1).clone()))
+        known = getattr(self.buffer, "known_mask_sum", None)
+        if known is not None and not _dist_on():
+            inv_denom = 1.0 / known  # the runner filed a whole episode: no device->host sync for masks.sum()
+        else:
+            inv_denom = 1.0 / float(all_reduce_sum_(masks.sum().reshape(1).clone()))
         losses = th.zeros(2, device=self.device)
         for _ in range(a.epochs):
             losses.zero_()

@@ -61,10 +61,20 @@ class TransitionStore:
                 _p(self._done), C.c_void_p(th.cuda.current_stream(e.device).cuda_stream)), "ec_store_episode")
         if buf is not None:
             buf.t = e.episode_limit
+            self._mark_whole_episode(buf)
+
+    def _mark_whole_episode(self, buf):
+        """the buffer holds one whole episode from reset, filed by the kernels: obs[:, t+1] and next_obs[:, t] are
+        copies of one observation, and only the last step terminates (edge_computing_env.py:139-142)"""
+        e = self.env
+        if hasattr(buf, "next_obs_is_shifted_obs"):
+            buf.next_obs_is_shifted_obs = True
+            buf.known_mask_sum = float(e.n_envs * e.n_agents * (e.episode_limit - 1))
 
     def initial(self, buf):
         """after reset + observe: obs[:, 0] / avail_actions[:, 0]"""
         self._call(-1, None, None, None, None, buf)
+        self._next_t = 0 if buf is not None else None  # steps filed in sequence since this call
 
     def step(self, t, actions, reward, terminated, info, buf):
         """after env.step(..., fuse_observe=True): transition t (+ the next step's observation) and the statistics;
@@ -72,3 +82,6 @@ class TransitionStore:
         self._call(t, actions, reward, terminated, info, buf)
         if buf is not None:
             buf.t = t + 1
+            self._next_t = t + 1 if getattr(self, "_next_t", None) == t else None
+            if self._next_t == self.env.episode_limit:
+                self._mark_whole_episode(buf)
