@@ -346,7 +346,8 @@ class DGAILAgent:
             with th.cuda.stream(side):
                 for _ in range(3):
                     idx = th.randint(0, rows, (mb,), device=self.device)
-                    bc = self.expert_transitions.sample_transitions(n_bc)
+                    # (warm-up only, undone below: no draw is taken from self.rng for it)
+                    bc = (self.expert_transitions.obs[:n_bc], self.expert_transitions.actions[:n_bc])
                     self._minibatch_step(g["policy_input"], g["act"], g["logp"], g["adv"], g["ret"], idx, bc, g["bc_w"],
                                          th.zeros(3, device=self.device))
             th.cuda.current_stream(self.device).wait_stream(side)

@@ -18,6 +18,9 @@ Groups
   gae      utils/advantage_utils.py:4-9 on random inputs
   expert10 / expert40   OptimalAgent.get_current_optimal_action (optimal/optimal_agent.py:102-120,166-375) on the
            states of replayed trajectories (expert-driven and expert/random mixtures)
+  mlp      the reference's torch modules on fixed inputs (logits, probabilities, discriminator rewards)
+  learn    the reference's PPOAgent / GAILAgent / DGAILAgent: one train() on a fixed buffer with every random draw
+           recorded => post-update state_dicts
 """
 import argparse
 import os
@@ -432,6 +435,214 @@ def gen_mlp():
 
 
 GROUPS["mlp"] = gen_mlp
+
+
+# --------------------------------------------------------------------------
+class _Recorder:
+    """Records, in call order, every random draw the reference's learners make inside an update, by wrapping the
+    library functions they call: np.random.choice (expert samples), th.randint / th.randn_like (compute_loss,
+    dgail_network.py:90-91), th.randperm (the DataLoader's shuffle) and F.dropout (GAIL discriminator)."""
+
+    def __init__(self):
+        self.draws = []
+
+    def __enter__(self):
+        import numpy as np
+        import torch as th
+        import torch.nn.functional as F
+        self._np_choice, self._randint, self._randn_like = np.random.choice, th.randint, th.randn_like
+        self._randperm, self._dropout = th.randperm, F.dropout
+        rec = self
+
+        def choice(a, size=None, replace=True, p=None):
+            r = rec._np_choice(a, size=size, replace=replace, p=p)
+            rec.draws.append(("choice", np.atleast_1d(np.asarray(r)).astype(np.int64)))
+            return r
+
+        def randint(*a, **k):
+            r = rec._randint(*a, **k)
+            rec.draws.append(("t", r.detach().cpu().numpy().astype(np.int64)))
+            return r
+
+        def randn_like(*a, **k):
+            r = rec._randn_like(*a, **k)
+            rec.draws.append(("noise", r.detach().cpu().numpy().copy()))
+            return r
+
+        def randperm(*a, **k):
+            r = rec._randperm(*a, **k)
+            rec.draws.append(("perm", r.detach().cpu().numpy().astype(np.int64)))
+            return r
+
+        def dropout(x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return x
+            keep = (th.rand_like(x) >= p)
+            rec.draws.append(("dropout", keep.cpu().numpy()))
+            return x * keep.to(x.dtype) / (1.0 - p)
+
+        np.random.choice, th.randint, th.randn_like, th.randperm, F.dropout = choice, randint, randn_like, randperm, dropout
+        return self
+
+    def __exit__(self, *exc):
+        import numpy as np
+        import torch as th
+        import torch.nn.functional as F
+        np.random.choice, th.randint, th.randn_like = self._np_choice, self._randint, self._randn_like
+        th.randperm, F.dropout = self._randperm, self._dropout
+
+    def dump(self, out, tag):
+        import numpy as np
+        out[tag + "draw_kinds"] = np.asarray([k for k, _ in self.draws])
+        for i, (_, v) in enumerate(self.draws):
+            out[tag + "draw_%04d" % i] = v
+
+
+def _learn_args(algo, extra):
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from default_config import add_default_args
+    from envs.edge_computing.multihop.edge_computing_config import add_edge_computing_env_args
+    from envs.env_register import env_register
+    adders = {}
+    from rl.policy_gradient_rl.ppo.ppo_config import add_ppo_args
+    from rl.policy_gradient_rl.gail.gail_config import add_gail_args
+    from rl.policy_gradient_rl.dgail.dgail_config import add_dgail_args
+    adders = {"ppo": add_ppo_args, "gail": add_gail_args, "dgail": add_dgail_args}
+    p = argparse.ArgumentParser(conflict_handler='resolve')
+    p = adders[algo](add_edge_computing_env_args(add_default_args(p)))
+    args = p.parse_args(extra)
+    args.device = "cpu"
+    env = env_register[args.env_name](args)          # main.py:37-43
+    info = env.get_env_info()
+    args.n_agents, args.n_actions = info["n_agents"], info["n_actions"]
+    args.obs_shape, args.state_shape = info["obs_shape"], info["state_shape"]
+    return args
+
+
+def _learn_rollout(args, agent, expert_every=0):
+    """One episode of args.n_threads reference envs (env k seeded as parallel_episode_runner.py:19-20) filed into
+    agent.buffer; the agent's own select_actions acts.  expert_every > 0: every expert_every-th step of env 0 also
+    stores the expert's (obs, action) pair with the agent (gail_runner.py:59-70 / dgail_runner.py:66-80)."""
+    import copy
+    import numpy as np
+    import torch as th
+    from envs.env_register import env_register
+    B, N = args.n_threads, args.n_agents
+    envs = []
+    for k in range(B):
+        a = copy.deepcopy(args)
+        a.task_seed += k
+        a.failure_seed += k
+        envs.append(env_register[a.env_name](a))
+    for e in envs:
+        e.reset()
+    for e in envs:  # reset leaves no task (edge_node.py:171-177): one idle step gives the episode something to do
+        e.step([N] * N)
+        e.current_step = 0
+    agent.buffer.reset()
+    for t in range(args.episode_limit):
+        obs = th.as_tensor(np.array([e.get_obs() for e in envs]), dtype=th.float)
+        avail = th.as_tensor(np.array([e.get_avail_actions() for e in envs]), dtype=th.int)
+        actions = agent.select_actions(obs, avail, False)
+        if expert_every and t % expert_every == 0:
+            ex = agent.get_expert_actions(envs[0])
+            agent.store_expert_data(obs[0], th.as_tensor(np.asarray(ex), dtype=th.long))
+        rewards, terms = [], []
+        for k, e in enumerate(envs):
+            r, term, _ = e.step(actions[k].cpu().numpy())
+            rewards.append(r)
+            terms.append(term)
+        next_obs = th.as_tensor(np.array([e.get_obs() for e in envs]), dtype=th.float)
+        rew = th.as_tensor(rewards, dtype=th.float).view(B, 1, 1).expand(B, N, 1)
+        masks = (1 - th.as_tensor(terms, dtype=th.float)).view(B, 1, 1).expand(B, N, 1)
+        agent.buffer.insert(obs, avail, actions.unsqueeze(-1), rew, masks, next_obs)
+
+
+def _dump_sd(out, tag, sd):
+    for k, v in sd.items():
+        out[tag + k] = v.detach().cpu().numpy().copy()
+
+
+def gen_learn():
+    """SURVEY 8c fixture (8): the reference's OWN learners on a fixed buffer.  Initial state_dicts + buffer + expert
+    transitions + every random draw made inside the update  =>  post-update state_dicts (and the returned stats)."""
+    import numpy as np
+    import torch as th
+    out = {}
+    th.set_num_threads(1)
+
+    # ---- PPOAgent.train (ppo_agent.py:85-134)
+    args = _learn_args("ppo", ["--task_size_max=6000", "--n_threads=4", "--episode_limit=20"])
+    from rl.policy_gradient_rl.ppo.ppo_agent import PPOAgent
+    np.random.seed(5)
+    th.manual_seed(5)
+    agent = PPOAgent(args)
+    _dump_sd(out, "ppo_actor0_", agent.actor.state_dict())
+    _dump_sd(out, "ppo_critic0_", agent.critic.state_dict())
+    _learn_rollout(args, agent)
+    for k in ("obs", "avail_actions", "actions", "rewards", "masks", "next_obs"):
+        out["ppo_buf_" + k] = getattr(agent.buffer, k).numpy().copy()
+    agent.train()
+    _dump_sd(out, "ppo_actor1_", agent.actor.state_dict())
+    _dump_sd(out, "ppo_critic1_", agent.critic.state_dict())
+    agent.train()  # a second update on the same buffer: Adam moments and the StepLR count carry over
+    _dump_sd(out, "ppo_actor2_", agent.actor.state_dict())
+    _dump_sd(out, "ppo_critic2_", agent.critic.state_dict())
+    out["ppo_cfg"] = np.asarray([args.n_threads, args.episode_limit, args.n_agents], dtype=np.int64)
+
+    # ---- GAILAgent.train (gail_agent.py:128-231)
+    args = _learn_args("gail", ["--task_size_max=6000", "--n_threads=2", "--episode_limit=20"])
+    from rl.policy_gradient_rl.gail.gail_agent import GAILAgent
+    np.random.seed(6)
+    th.manual_seed(6)
+    agent = GAILAgent(args)
+    for name in ("actor", "critic", "discriminator"):
+        _dump_sd(out, "gail_%s0_" % name, getattr(agent, name).state_dict())
+    _learn_rollout(args, agent, expert_every=1)       # 20 expert transitions (>= 10: the discriminator trains)
+    for k in ("obs", "avail_actions", "actions", "rewards", "masks", "next_obs"):
+        out["gail_buf_" + k] = getattr(agent.buffer, k).numpy().copy()
+    out["gail_expert_obs"] = th.stack(agent.expert_obs_buffer).numpy()
+    out["gail_expert_actions"] = th.stack(agent.expert_actions_buffer).numpy()
+    agent.performance_history = [0.5, 0.6, 0.9, 0.4, 0.6]   # mean < 0.7: the BC weight grows (:118-126)
+    with _Recorder() as rec:
+        agent.train()
+    rec.dump(out, "gail_")
+    for name in ("actor", "critic", "discriminator"):
+        _dump_sd(out, "gail_%s1_" % name, getattr(agent, name).state_dict())
+    out["gail_bc_weight1"] = np.float64(agent.bc_loss_weight)
+    out["gail_cfg"] = np.asarray([args.n_threads, args.episode_limit, args.n_agents], dtype=np.int64)
+
+    # ---- DGAILAgent.train (dgail_agent.py:335-381): BC pretrain, both discriminators, rewards, minibatch PPO
+    for tag, extra in (("dgail_", []), ("dgaild_", ["--use_simplified_reward="])):
+        args = _learn_args("dgail", ["--task_size_max=6000", "--n_threads=1", "--episode_limit=25", "--batch_size_run=10"]
+                           + extra)
+        from rl.policy_gradient_rl.dgail.dgail_agent import DGAILAgent
+        np.random.seed(7)
+        th.manual_seed(7)
+        agent = DGAILAgent(args)
+        nets = ("policy", "value", "discriminator", "gail_discriminator")
+        for name in nets:
+            _dump_sd(out, tag + name + "0_", getattr(agent, name).state_dict())
+        _learn_rollout(args, agent, expert_every=1)   # 25 expert transitions
+        for k in ("obs", "avail_actions", "actions", "rewards", "masks", "next_obs"):
+            out[tag + "buf_" + k] = getattr(agent.buffer, k).numpy().copy()
+        out[tag + "expert_obs"] = th.stack([t[0] for t in agent.expert_transitions]).numpy()
+        out[tag + "expert_actions"] = th.stack([t[1] for t in agent.expert_transitions]).numpy()
+        agent._bc_pretrain_steps = 6                  # 700 in the reference (:92): same code, fewer steps
+        with _Recorder() as rec:
+            stats = agent.train(5000)
+        rec.dump(out, tag)
+        for name in nets:
+            _dump_sd(out, tag + name + "1_", getattr(agent, name).state_dict())
+        out[tag + "stat_keys"] = np.asarray(sorted(stats))
+        out[tag + "stat_vals"] = np.asarray([float(stats[k]) for k in sorted(stats)], dtype=np.float64)
+        out[tag + "use_simplified_reward"] = np.int64(bool(args.use_simplified_reward))
+        out[tag + "cfg"] = np.asarray([args.n_threads, args.episode_limit, args.n_agents], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "learn.npz"), **out)
+
+
+GROUPS["learn"] = gen_learn
 
 
 if __name__ == "__main__":

@@ -190,6 +190,27 @@ def test_expert_transitions_fifo():
     assert len(st3) == 4
 
 
+def test_expert_transitions_more_rows_than_capacity():
+    """One append can select more envs than the ring holds (n_threads > max_expert_buffer_size): the FIFO keeps the
+    newest `capacity` of them, every slot from exactly one source row, (obs, action) pairs intact -- what appending
+    the rows one by one (gail_agent.py:77-83) would leave."""
+    from marl_amd.buffer.expert_transitions import ExpertTransitions
+    cap, B, N = 5, 23, 3
+    st = ExpertTransitions(cap, N, 9, "cpu")
+    for rnd in range(3):
+        ids = th.arange(B) + 100 * rnd
+        obs = ids.view(B, 1, 1).expand(B, N, 9).float().contiguous()   # every element of a row carries the row id
+        act = ids.view(B, 1).expand(B, N).contiguous()
+        select = th.ones(B, dtype=th.bool) if rnd != 1 else (th.arange(B) % 2 == 0)
+        st.append(obs, act, select)
+        assert len(st) == cap
+        chosen = ids[select][-cap:]                                    # newest `cap` selected rows
+        got_obs, got_act = st.obs[:cap], st.actions[:cap]
+        assert th.equal(got_obs[:, 0, 0].long(), got_act[:, 0])        # pairs stay matched
+        assert (got_obs == got_obs[:, :1, :1]).all() and (got_act == got_act[:, :1]).all()  # no element-wise mixing
+        assert sorted(got_act[:, 0].tolist()) == sorted(chosen.tolist())
+
+
 def _imitation_args(kind, B):
     from marl_amd.default_config import add_default_args
     from marl_amd.envs.edge_computing.multihop.edge_computing_config import add_edge_computing_env_args
