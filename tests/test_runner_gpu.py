@@ -418,6 +418,91 @@ def test_kernel_rollout_equals_per_step_rollout():
     assert all(t.shape == b.shape for t, b in zip(agent.buffer.sample(), before))
 
 
+def test_buffer_contents_three_writers_and_oracle(oracle_lib):
+    """EpisodeBuffer contents (buffer/episode_buffer.py:21-28, parallel_episode_runner.py:101-113), independently of
+    the store kernels: the same two episodes filed by (i) the runner's torch `insert` branch, (ii) ec_store_transition
+    per step and (iii) ec_store_episode after the one-launch rollout give identical tensors, and what they hold is what
+    the CPU oracle observes / returns when it replays the stored actions (obs[:, t], avail[:, t], team reward, mask,
+    next_obs[:, t])."""
+    from marl_amd import _abi
+    from marl_amd.agent_register import agent_register
+    from marl_amd.runners.runner_register import runner_register
+    from marl_amd.utils import mlp_device
+    from oracle.ec_oracle import OracleEnv
+    B, T, base = 70, 25, 9
+
+    def make(kernel):
+        args = _args(B, ec_env_id_base=base, episode_limit=T, ec_kernel_rollout=kernel, ec_hop_hist_len=32)
+        th.manual_seed(11)
+        agent = agent_register["ppo"](args)
+        with th.no_grad():
+            for p in agent.actor.parameters():
+                p.mul_(4.0)
+        agent.train = lambda: None
+        return args, agent, runner_register["parallel"](args, agent)
+
+    # (iii) one launch per episode + ec_store_episode; its uniforms drive the other two writers
+    args, agent, runner = make(1)
+    assert runner._kernel_rollout_ok()
+    bufs3, us = [], []
+    for ep in range(2):
+        runner.run(test_mode=False)
+        bufs3.append([t.clone() for t in agent.buffer.sample()])
+        us.append(runner._uniforms.clone())
+        assert agent.buffer.next_obs_is_shifted_obs and agent.buffer.known_mask_sum == B * args.n_agents * (T - 1)
+    tables = runner.env.tables
+    runner.close_env()
+
+    def replay(torch_insert):
+        args2, agent2, runner2 = make(0)
+        if torch_insert:
+            runner2._store.usable = lambda buf: False   # the runner's own torch-op branch (:143-154)
+        state = {"ep": 0, "t": 0}
+
+        def select(obs, avail, test_mode=False):
+            u = us[state["ep"]][state["t"]]
+            state["t"] += 1
+            _, _, a = mlp_device.policy_forward(mlp_device.linear_params(agent2.actor), obs.contiguous(), args2.n_agents,
+                                                avail.contiguous(), u, want_probs=False)
+            return a.view(obs.shape[:-1])
+
+        agent2.select_actions = select
+        out = []
+        for ep in range(2):
+            state["ep"], state["t"] = ep, 0
+            runner2.run(test_mode=False)
+            out.append([t.clone() for t in agent2.buffer.sample()])
+            assert agent2.buffer.next_obs_is_shifted_obs == (not torch_insert)
+        runner2.close_env()
+        return out
+
+    bufs1 = replay(True)    # (i)
+    bufs2 = replay(False)   # (ii)
+    names = ("obs", "avail_actions", "actions", "rewards", "masks", "next_obs")
+    for ep in range(2):
+        for name, x, y, z in zip(names, bufs1[ep], bufs2[ep], bufs3[ep]):
+            assert th.equal(x, y), (ep, name, "torch insert vs ec_store_transition")
+            assert th.equal(x, z), (ep, name, "torch insert vs ec_store_episode")
+
+    # against the oracle: replay the stored actions
+    orc = OracleEnv(_abi.config_from_args(args, hop_hist_len=32), tables, B, env_id_base=base, n_threads=4)
+    for ep in range(2):
+        obs, avail, actions, rewards, masks, next_obs = [t.cpu().numpy() for t in bufs3[ep]]
+        orc.reset()
+        for t in range(T):
+            o, av = orc.observe()
+            assert np.array_equal(obs[:, t], o.astype(np.float32)), (ep, t, "obs")
+            assert np.array_equal(avail[:, t], av), (ep, t, "avail")
+            out = orc.step(actions[:, t, :, 0])
+            assert out["bad"] == 0
+            r = out["reward"].astype(np.float32)
+            assert np.array_equal(rewards[:, t, :, 0], np.repeat(r[:, None], args.n_agents, 1)), (ep, t, "reward")
+            assert np.array_equal(masks[:, t, :, 0], np.full((B, args.n_agents), 0.0 if t == T - 1 else 1.0, np.float32))
+            o2, _ = orc.observe()
+            assert np.array_equal(next_obs[:, t], o2.astype(np.float32)), (ep, t, "next_obs")
+    orc.close()
+
+
 def test_gail_fused_update_matches_torch_update():
     """GAILAgent PPO part: fused kernels + autograd BC term accumulated into the same flat buffer vs pure autograd."""
     from marl_amd.agent_register import agent_register
