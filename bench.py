@@ -17,8 +17,11 @@ Every step writes its reward, counters, termination flag, observation, mask and 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  Multi-GPU: environments are independent, so rank r owns env ids
-[r*B, (r+1)*B) (same seeds as a single 8*B batch) and there is no data-path collective: weak scaling.
+Rank 0 prints ONE JSON line.  Multi-GPU: BASELINE.json's metric is quoted for 4096 envs on the WHOLE node, so
+--gpus N shards those 4096 envs (rank r owns env ids [r*4096/N, (r+1)*4096/N): same seeds, hence same trajectories,
+as the single-GPU batch; no data-path collective) and the line says "scaling": "strong".  The weak-scaling figure
+(4096 envs per GPU) rides beside it under "weak_scaling", and "ppo_iteration" times rollout + update on all ranks
+with the learner's flat-gradient all-reduce over RCCL.
 """
 import argparse
 import json
@@ -38,12 +41,15 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=1000)
     p.add_argument("--warmup", type=int, default=200)
-    p.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    p.add_argument("--envs", type=int, default=4096, help="environments of the whole job (sharded over --gpus)")
     p.add_argument("--nodes", type=int, default=10, help="edge_node_num")
     p.add_argument("--launch", choices=("rollout", "graph", "eager"), default="rollout")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
     p.add_argument("--roofline-steps", type=int, default=400)
     p.add_argument("--geometry", default="", help="override the step kernel's launch geometry: epw,mw[,producers]")
+    p.add_argument("--rehearse", action="store_true",
+                   help="multi-rank logic on a box with ONE GPU: every rank uses cuda:0 and the process group is gloo "
+                        "(not a measurement: the line is marked)")
     p.add_argument("--ppo-iters", type=int, default=3,
                    help="also time this many PPO iterations (rollout + update) at N=1 and report them beside the metric")
     return p.parse_args()
@@ -200,32 +206,41 @@ def cpu_baseline(args_ns, tables, n_envs, budget_s):
             "sample": "%d envs x %d steps (observe + random policy + step), OpenMP C oracle, %.1f s" % (n_envs, steps, dt)}
 
 
-def ppo_iterations(ns, B, N, iters):
+def ppo_iterations(ns, B, N, iters, rank=0, world=1, trace=lambda m: None):
     """BASELINE.json's second figure: wall time of one PPO iteration = ParallelRunner.run(test_mode=False):
     the episode as one ec_rollout_mlp_policy launch (Actor + env step, episode_limit times, for all B envs) and one
     ec_store_episode launch into the device buffer, then PPOAgent.train() (reward normalisation, GAE kernel, `epochs` full-batch actor/critic updates)."""
     import torch as th
     from marl_amd.agent_register import agent_register
     from marl_amd.runners.runner_register import runner_register
+    import torch.distributed as dist
     ns.n_threads, ns.algo_type, ns.obs_shape, ns.n_agents, ns.n_actions = B, "rl", 9, N, N + 1
     ns.ec_graph_rollout = True  # only used where ec_rollout_mlp_policy is not compiled for the env shape
-    th.manual_seed(100)
+    ns.ec_env_id_base = rank * B  # this rank's shard of the job's envs
+    th.manual_seed(100 + rank)
     agent = agent_register["ppo"](ns)
+    trace("ppo: agent built")
     runner = runner_register["parallel"](ns, agent)
+    trace("ppo: runner built")
     train = agent.train
     spans = []
 
     def timed_train():
         th.cuda.synchronize()
+        trace("ppo: rollout done, train")
         t0 = time.perf_counter()
         train()
         th.cuda.synchronize()
         spans.append(time.perf_counter() - t0)
+        trace("ppo: train done")
 
     agent.train = timed_train
     total = []
-    for it in range(iters + 1):  # first iteration is warm-up (allocator, kernel load)
+    for it in range(iters + 1):  # first iteration is warm-up (allocator, kernel load, RCCL communicator)
         th.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            th.cuda.synchronize()
         t0 = time.perf_counter()
         runner.run(test_mode=False)
         th.cuda.synchronize()
@@ -234,11 +249,17 @@ def ppo_iterations(ns, B, N, iters):
     runner.close_env()
     total, upd = sorted(total[1:]), sorted(spans[1:])
     med = lambda v: v[len(v) // 2]
-    return {"total_ms": 1e3 * med(total), "update_ms": 1e3 * med(upd), "rollout_ms": 1e3 * (med(total) - med(upd)),
-            "iters": iters, "envs": B, "agents": N, "episode_limit": ns.episode_limit, "epochs": ns.epochs,
-            "rows_per_update": B * N * ns.episode_limit,
+    t_tot, t_upd = med(total), med(upd)
+    if world > 1:  # the iteration is over when the slowest rank is
+        t = th.tensor([t_tot, t_upd], dtype=th.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_tot, t_upd = t.tolist()
+    return {"total_ms": 1e3 * t_tot, "update_ms": 1e3 * t_upd, "rollout_ms": 1e3 * (t_tot - t_upd),
+            "iters": iters, "envs": B * world, "envs_per_gpu": B, "agents": N, "episode_limit": ns.episode_limit,
+            "epochs": ns.epochs, "rows_per_update": B * world * N * ns.episode_limit,
             "rollout": mode,
-            "rollout_agent_steps_per_s": B * N * ns.episode_limit / (med(total) - med(upd))}
+            "gradient_all_reduce": "one flat buffer per optimiser step over RCCL (nccl backend)" if world > 1 else None,
+            "rollout_agent_steps_per_s": B * world * N * ns.episode_limit / (t_tot - t_upd)}
 
 
 def main():
@@ -253,9 +274,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (a.gpus, world))
+    if a.rehearse:
+        local = 0
     th.cuda.set_device(local)
     dev = th.device("cuda:%d" % local)
-    if world > 1:
+    if world > 1 and a.rehearse:
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=dev)
     if a.geometry:  # "envs per wave, main waves[, 0 = no RNG producer waves]" (default: chosen by ec_create)
         g = [int(x) for x in a.geometry.split(",")]
@@ -263,10 +288,19 @@ def main():
         if len(g) > 2:
             os.environ["MARL_AMD_EC_PRODUCERS"] = str(g[2])
 
+    def trace(msg):  # stage markers on stderr (MARL_AMD_BENCH_TRACE=1): where a multi-rank run is, per rank
+        if os.environ.get("MARL_AMD_BENCH_TRACE"):
+            print("[bench rank %d %.1fs] %s" % (rank, time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
+    if os.environ.get("MARL_AMD_BENCH_TRACE", "").isdigit() and int(os.environ["MARL_AMD_BENCH_TRACE"]) > 1:
+        import faulthandler  # where every thread is if the run is still going after that many seconds
+        faulthandler.dump_traceback_later(int(os.environ["MARL_AMD_BENCH_TRACE"]), exit=True)
     ns = make_args(["--task_size_max=6000", "--seed=100", "--edge_node_num=%d" % a.nodes])
-    B, N = a.envs, a.nodes
-    env = BatchedEdgeComputingEnv(ns, n_envs=B, env_id_base=rank * B, device=dev)
-    roll = Rollout(env, a.launch)
+    N = a.nodes
+    if a.envs % world:
+        raise SystemExit("--envs %d is not a multiple of --gpus %d" % (a.envs, world))
+    B = a.envs // world  # this rank's shard: strong scaling of the job BASELINE.json names
 
     def fence():
         th.cuda.synchronize(dev)
@@ -274,19 +308,28 @@ def main():
             dist.barrier()
             th.cuda.synchronize(dev)
 
-    roll.run(a.warmup)
-    fence()
-    t0 = time.perf_counter()
-    roll.run(a.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = th.tensor([dt], dtype=th.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    st = env.status()
-    if st & ~32:
-        raise SystemExit("device status 0x%x after the timed region" % st)
+    def timed(envs_per_rank):
+        """W untimed + K timed steps of envs_per_rank envs on every rank; max over ranks"""
+        env_ = BatchedEdgeComputingEnv(ns, n_envs=envs_per_rank, env_id_base=rank * envs_per_rank, device=dev)
+        roll_ = Rollout(env_, a.launch)
+        roll_.run(a.warmup)
+        fence()
+        t0 = time.perf_counter()
+        roll_.run(a.steps)
+        fence()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            t = th.tensor([dt_], dtype=th.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        st = env_.status()
+        if st & ~32:
+            raise SystemExit("device status 0x%x after the timed region" % st)
+        return env_, roll_, dt_
+
+    trace("process group up")
+    env, roll, dt = timed(B)
+    trace("timed region done: %.3f s" % dt)
 
     out = None
     if rank == 0:
@@ -294,21 +337,24 @@ def main():
         out = {
             "metric": "env agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64/u32", "data": "synthetic",
-            "config": {"workload": "edge_computing env step, %d envs/GPU x %d agents, task_size_max=6000, "
-                                   "uniform-random policy over the avail mask, reset every %d steps "
-                                   "(BASELINE.json configs[1])" % (B, N, env.episode_limit),
-                       "envs_per_gpu": B, "agents": N,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64/u32", "data": "synthetic",
+            "config": {"workload": "edge_computing env step, %d envs in all (%d per GPU on %d GPU%s) x %d agents, "
+                                   "task_size_max=6000, uniform-random policy over the avail mask, reset every %d "
+                                   "steps (BASELINE.json configs[%d])"
+                                   % (B * world, B, world, "" if world == 1 else "s", N, env.episode_limit,
+                                      1 if world == 1 else 2),
+                       "envs_total": B * world, "envs_per_gpu": B, "agents": N,
                        "launch": {"rollout": "ec_rollout_random_policy, one launch per episode",
                                   "graph": "ec_step_random_policy per step, hipGraph per episode",
                                   "eager": "ec_step_random_policy per step, eager"}[a.launch],
                        "geometry": env.info_geometry()},
         }
-    if rank == 0 and world == 1:
+    if rank == 0:
+        # the dominant kernel on rank 0's shard (no collectives inside; the other ranks wait at the next barrier)
         avg_ms, med_ms, ravg_ms, rmed_ms, lbar, draws = measure_roofline(env, roll, a.roofline_steps)
         bytes_step = algorithmic_bytes_per_env_step(N, lbar, draws) * B
         T = env.episode_limit
-        std = B == 4096 and N == 10
+        std = B == 4096 and N == 10 and world == 1
         one = {"bound": "hbm", "achieved": bytes_step / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "kernel": "k_step<.., one step>", "env_steps_per_launch": 1,
                "kernel_avg_us": avg_ms * 1e3, "kernel_median_us": med_ms * 1e3,
@@ -327,16 +373,41 @@ def main():
         other = one if a.launch == "rollout" else many
         other["agent_steps_per_s_kernel_only"] = B * N * other["env_steps_per_launch"] / (other["kernel_avg_us"] * 1e-6)
         out["per_step_launch" if a.launch == "rollout" else "rollout_launch"] = other
-        if a.cpu_seconds > 0:
+        trace("roofline done")
+        if a.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(ns, env.tables, B, a.cpu_seconds)
+            # the reference itself cannot travel to the GPU box: its own figures, measured where it is importable
+            out["cpu_baseline"]["reference_python"] = {
+                "rollout_agent_steps_per_s": 32000.0, "env_only_agent_steps_per_s_1core": 24000.0, "cores": 8,
+                "what": "the reference's ParallelRunner + PPO policy, n_threads=8 (3 iterations: 0.75 s rollout + "
+                        "0.32 s update); single env, random-valid policy on one core for the second figure",
+                "where": "measured in the build container by importing /root/reference (SURVEY.md section 6), "
+                         "not on this box: a recorded constant, not a measurement of this run"}
     env.close()
-    if rank == 0 and world == 1 and a.ppo_iters > 0:
-        del roll
-        out["ppo_iteration"] = ppo_iterations(ns, B, N, a.ppo_iters)
+    del roll
+    if world > 1 and a.envs * world <= 65536:
+        # weak scaling beside it: --envs environments on EVERY rank (what round 1 reported as the N > 1 value)
+        trace("weak-scaling run")
+        env_w, roll_w, dt_w = timed(a.envs)
+        trace("weak-scaling run done: %.3f s" % dt_w)
+        env_w.close()
+        del roll_w
+        if rank == 0:
+            out["weak_scaling"] = {"envs_per_gpu": a.envs, "envs_total": a.envs * world,
+                                   "value": world * a.envs * N * a.steps / dt_w, "unit": "agent-steps/s",
+                                   "ms_per_step": 1e3 * dt_w / a.steps}
+    if a.ppo_iters > 0:
+        trace("ppo iterations")
+        ppo = ppo_iterations(ns, B, N, a.ppo_iters, rank, world, trace)
+        trace("ppo iterations done")
+        if rank == 0:
+            out["ppo_iteration"] = ppo
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if a.rehearse:
+            out["rehearsal"] = "all ranks on one GPU over gloo: checks the multi-rank code path, measures nothing"
         print(json.dumps(out), flush=True)
 
 

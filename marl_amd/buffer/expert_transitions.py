@@ -23,6 +23,17 @@ class ExpertTransitions:
         """len(self.expert_transitions) of the reference (synchronises)."""
         return int(min(int(self._written.item()), self.capacity))
 
+    def global_len(self):
+        """len() as the ranks agree on it: the minimum over ranks.  Branches that lead into collective code (train or
+        skip, discriminator step or not) must be taken by every rank alike, whatever its own expert coin flips stored;
+        with no process group this is len()."""
+        import torch.distributed as dist
+        n = len(self)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from marl_amd.utils.dist_utils import all_reduce_
+            n = int(all_reduce_(th.tensor([n], dtype=th.int64, device=self.device), dist.ReduceOp.MIN).item())
+        return n
+
     def append(self, obs, actions, select=None):
         """obs [B,N,O], actions [B,N]; select: optional bool [B] (envs whose transition is stored)."""
         B = obs.shape[0]

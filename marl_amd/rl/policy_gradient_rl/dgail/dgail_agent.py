@@ -386,9 +386,9 @@ class DGAILAgent:
 
     def train(self, t_env):
         """One training iteration on the rollout in the buffer, dgail_agent.py:335-381."""
-        if len(self.expert_transitions) < self.args.batch_size_run:
-            print("Insufficient expert data (%d/%d), skip this training." % (len(self.expert_transitions),
-                                                                            self.args.batch_size_run))
+        n_expert = self.expert_transitions.global_len()  # every rank takes the same branch (collectives follow)
+        if n_expert < self.args.batch_size_run:
+            print("Insufficient expert data (%d/%d), skip this training." % (n_expert, self.args.batch_size_run))
             return None
         if self._bc_pretrain_steps > 0:
             self._bc_pretrain()

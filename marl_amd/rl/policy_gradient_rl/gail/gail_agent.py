@@ -178,7 +178,9 @@ class GAILAgent:
             ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, old_logp=old_logp, adv=advantages,
                                   eps_clip=a.eps_clip, entropy_coef=a.entropy_coef if a.use_entropy else 0.0,
                                   inv_denom=inv_denom, grads=self._fg_actor.flat, loss=losses[1:2])
-            (self.bc_loss_weight * self.compute_bc_loss() / world_size()).backward()
+            bc_loss = self.compute_bc_loss()
+            if bc_loss.requires_grad:  # (a constant zero while no expert transition is stored, :86-87)
+                (self.bc_loss_weight * bc_loss / world_size()).backward()
             all_reduce_sum_(self._fg_actor.flat)
             if a.use_grad_clip:
                 th.nn.utils.clip_grad_norm_(self.actor.parameters(), a.grad_norm_clip)
@@ -191,7 +193,7 @@ class GAILAgent:
         a = self.args
         obs, avail_actions, actions, rewards, masks, next_obs = self.buffer.sample()
         obs_id = self._with_ids(obs)
-        if len(self.expert_transitions) >= 10:
+        if self.expert_transitions.global_len() >= 10:  # the ranks' minimum: all of them step, or none
             rewards = self._discriminator_step(obs_id, actions)
         if self._fg_actor is not None:
             del obs_id

@@ -24,7 +24,8 @@ from marl_amd.utils.advantage_utils import get_gae
 from marl_amd.utils import mlp_device, ppo_device
 
 
-from marl_amd.utils.dist_utils import all_reduce_grads_, all_reduce_sum_, dist_on as _dist_on, global_mean_std  # noqa: E402,F401
+from marl_amd.utils.dist_utils import (all_reduce_grads_, all_reduce_sum_, broadcast_params_, dist_on as _dist_on,
+                                       global_mean_std)  # noqa: E402,F401
 
 
 class PPOAgent:
@@ -35,8 +36,7 @@ class PPOAgent:
         self.actor = Actor(args).to(self.device)
         self.critic = Critic(args).to(self.device)
         if _dist_on():  # identical initial parameters on every rank
-            for p in list(self.actor.parameters()) + list(self.critic.parameters()):
-                dist.broadcast(p.data, src=0)
+            broadcast_params_([self.actor, self.critic])
         kw = dict(lr=args.lr)
         if args.use_adm_epsilon:
             kw["eps"] = args.adam_epsilon

@@ -12,7 +12,7 @@ import torch.distributed as dist
 
 from marl_amd.envs.env_register import env_register
 from marl_amd.runners._transition_store import TransitionStore
-from marl_amd.utils.dist_utils import dist_on
+from marl_amd.utils.dist_utils import all_reduce_, dist_on
 
 
 class DGAILRunner:
@@ -129,9 +129,9 @@ class DGAILRunner:
         n_envs = th.tensor([float(B)], dtype=th.float64, device=totals.device)
         hops = env.hop_hist.double().sum(0)
         if dist_on():
-            dist.all_reduce(totals)
-            dist.all_reduce(n_envs)
-            dist.all_reduce(hops)
+            all_reduce_(totals)
+            all_reduce_(n_envs)
+            all_reduce_(hops)
         ret, ctime, fin, succ, drop, fail = totals.tolist()
         self.expert_steps = int(n_expert.item())
         finish_cnt = max(fin, 1)
@@ -144,7 +144,8 @@ class DGAILRunner:
             "task_completion_time": ctime / success_base,
             "max_hop_dict": {h: int(c) for h, c in enumerate(hops.tolist()) if c},
             "episode_steps": steps,
-            "expert_buffer_size": len(self.agent.expert_transitions),
+            # (the ranks' minimum under torch.distributed: the train-or-skip decision below leads into collectives)
+            "expert_buffer_size": self.agent.expert_transitions.global_len(),
         }
         if not test_mode and ep_info["expert_buffer_size"] > args.batch_size_run:   # :127-131
             train_stats = self.agent.train(self.t_env)

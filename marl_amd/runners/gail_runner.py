@@ -8,7 +8,7 @@ import torch.distributed as dist
 
 from marl_amd.envs.env_register import env_register
 from marl_amd.runners._transition_store import TransitionStore
-from marl_amd.utils.dist_utils import dist_on
+from marl_amd.utils.dist_utils import all_reduce_, dist_on
 
 
 class GAILRunner:
@@ -102,9 +102,9 @@ class GAILRunner:
         n_envs = th.tensor([float(B)], dtype=th.float64, device=totals.device)
         hops = env.hop_hist.double().sum(0)
         if dist_on():
-            dist.all_reduce(totals)
-            dist.all_reduce(n_envs)
-            dist.all_reduce(hops)
+            all_reduce_(totals)
+            all_reduce_(n_envs)
+            all_reduce_(hops)
         ret, ctime, fin, succ, drop, fail = totals.tolist()
         episode_info = {
             "episode_return": ret / n_envs.item(),

@@ -24,6 +24,8 @@ the captured environments' RNG streams are untouched and trajectories equal the 
 import torch as th
 import torch.distributed as dist
 
+from marl_amd.utils.dist_utils import all_reduce_
+
 from marl_amd.envs.env_register import env_register
 from marl_amd.runners._transition_store import TransitionStore
 
@@ -161,9 +163,9 @@ class ParallelRunner:
         n_envs = th.tensor([float(B)], dtype=th.float64, device=totals.device)
         hops = env.hop_hist.double().sum(0)
         if _dist_on():
-            dist.all_reduce(totals)
-            dist.all_reduce(n_envs)
-            dist.all_reduce(hops)
+            all_reduce_(totals)
+            all_reduce_(n_envs)
+            all_reduce_(hops)
         ret, ctime, fin, succ, drop, fail = totals.tolist()
         episode_info = {
             "episode_return": ret / n_envs.item(),

@@ -14,10 +14,29 @@ def world_size():
     return dist.get_world_size() if dist_on() else 1
 
 
-def all_reduce_sum_(t):
-    if dist_on():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+def _host_staged():
+    """gloo moves bytes through host memory anyway, and its device-tensor path is not dependable on every build: with
+    a gloo group, device tensors are reduced through a host copy (rehearsals on one GPU, CPU tests).  nccl (RCCL)
+    reduces device tensors in place, stream-ordered."""
+    return dist.get_backend() == "gloo"
+
+
+def all_reduce_(t, op=None):
+    """in-place all-reduce of `t` over all ranks (identity with no process group)"""
+    if not dist_on():
+        return t
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and _host_staged():
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
     return t
+
+
+def all_reduce_sum_(t):
+    return all_reduce_(t)
 
 
 def all_reduce_grads_(params, average=False):
@@ -28,7 +47,7 @@ def all_reduce_grads_(params, average=False):
     if not grads:
         return
     flat = th.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    all_reduce_(flat)
     if average:
         flat /= dist.get_world_size()
     off = 0
@@ -38,13 +57,25 @@ def all_reduce_grads_(params, average=False):
         off += n
 
 
+def broadcast_(t, src=0):
+    if not dist_on():
+        return t
+    if t.is_cuda and _host_staged():
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+    return t
+
+
 def broadcast_params_(modules, src=0):
     """identical initial parameters (and buffers) on every rank"""
     if not dist_on():
         return
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
-            dist.broadcast(t.data, src=src)
+            broadcast_(t.data, src)
 
 
 def global_mean_std(x):

@@ -503,6 +503,64 @@ def test_buffer_contents_three_writers_and_oracle(oracle_lib):
     orc.close()
 
 
+def test_gail_runner_n40_expert_in_lockstep_with_oracle(oracle_lib):
+    """BASELINE configs[4] shape (edge_node_num=40, GAIL): GAILRunner + GAILAgent for two iterations on the scaled
+    topology.  During expert guidance (ratio 1.0 below bc_guidance_steps, gail_agent.py:68-75) every env executes the
+    expert's action; an oracle env batch is driven by the same actions in lock step and its expert
+    (oc_expert_policy = optimal_agent.py:102-120,166-375 restated) must agree with ec_expert_policy at every step, as
+    must observation, mask and reward."""
+    from marl_amd import _abi
+    from marl_amd.agent_register import agent_register
+    from marl_amd.runners.runner_register import runner_register
+    from oracle.ec_oracle import OracleEnv
+    B, N, T, base = 40, 40, 20, 2
+    a = _imitation_args("gail", B, edge_node_num=N, n_agents=N, n_actions=N + 1, state_shape=9 * N, episode_limit=T,
+                        ec_env_id_base=base, ec_hop_hist_len=32)
+    th.manual_seed(9)
+    agent = agent_register["gail"](a)
+    assert agent._fused_ok() and agent._fg_actor is not None     # N + 1 = 41 actions: still the HIP policy / update path
+    runner = runner_register["gail_runner"](a, agent)
+    orc = OracleEnv(_abi.config_from_args(a, hop_hist_len=32), runner.env.tables, B, env_id_base=base, n_threads=4)
+    state = {"t": 0, "checked": 0}
+    inner = agent.get_expert_actions
+
+    def get_expert_actions(env):
+        acts = inner(env)
+        o, av = orc.observe()
+        assert np.array_equal(env.obs.cpu().numpy(), o.astype(np.float32)), state
+        assert np.array_equal(env.avail.cpu().numpy(), av), state
+        want = orc.expert_policy(av)
+        assert np.array_equal(acts.cpu().numpy(), want), state
+        out = orc.step(want)                                     # ratio 1.0: the expert's action is what env.step gets
+        assert out["bad"] == 0
+        state["reward"] = out["reward"].astype(np.float32)
+        state["t"] += 1
+        state["checked"] += 1
+        return acts
+
+    agent.get_expert_actions = get_expert_actions
+    step = runner.env.step
+
+    def checked_step(actions, **kw):
+        r = step(actions, **kw)
+        assert np.array_equal(r[0].cpu().numpy(), state["reward"]), state["t"]
+        return r
+
+    runner.env.step = checked_step
+    for it in range(2):
+        orc.reset()
+        info = runner.run(test_mode=False, t_expert=it * B * T)
+        assert it * B * T + B * T <= a.bc_guidance_steps        # still ratio 1.0
+        assert np.isfinite(info["episode_return"]) and all(bool(th.isfinite(v)) for v in agent.last_losses.values())
+        assert "discriminator_loss" in agent.last_losses        # >= 10 expert transitions: the discriminator trained
+    assert state["checked"] == 2 * T and len(agent.expert_transitions) == min(2 * T * B, a.max_expert_buffer_size)
+    n = len(agent.expert_transitions)
+    ea = agent.expert_transitions.actions[:n]
+    assert int(ea.max()) <= N and int((ea < N).sum()) > 0      # neighbours / self, or idle (N) without a task
+    runner.close_env()
+    orc.close()
+
+
 def test_gail_fused_update_matches_torch_update():
     """GAILAgent PPO part: fused kernels + autograd BC term accumulated into the same flat buffer vs pure autograd."""
     from marl_amd.agent_register import agent_register
