@@ -1038,7 +1038,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                                           uint8_t* __restrict__ terminated, int32_t* __restrict__ counters,
                                           float* __restrict__ completion_time, float* __restrict__ next_obs,
                                           int32_t* __restrict__ next_avail, StepPolicy pol, StepCarry<KMAX, DMAX>& cr,
-                                          const bool first, const bool last) {
+                                          const bool first, const bool last, const int* s_pick = nullptr) {
     static_assert(RB_FAIL >= KMAX + DMAX, "failure window too small");
     static_assert(RB_FAIL * 4 >= 12 + 36, "observation scratch does not fit the failure window");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1361,6 +1361,17 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
     EC_STAMP_P(11);
     __syncthreads();
     EC_STAMP(1);
+    // ec_rollout_mlp_policy: the Actor rows beyond a main wave's first 32 were evaluated by a producer wave, which left
+    // the actions in LDS ahead of this barrier (k_rollout_mlp)
+    if (s_pick && L.valid && (threadIdx.x & 63u) >= 32u) {
+        action = s_pick[tid];
+        slot = -1;
+        rate = 0.0;
+        if (has_new && action >= 0 && action < N && action != node) {
+            slot = d.slot_of[node * N + (int)action];
+            rate = d.rate[node * N + (int)action];
+        }
+    }
 
     // ---------------------------------------------------------------- phase A: offload_task, edge_node.py:199-234
     if (L.valid && has_new && action != N) {
@@ -2217,6 +2228,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
 #endif
     extern __shared__ __align__(16) unsigned char smem_all[];
     float* s_b23 = reinterpret_cast<float*>(smem_all + m.b23_lds);
+    int* s_pick = reinterpret_cast<int*>(s_b23 + polinl::H + 32);  // [main lanes] actions handed over by producer waves
     for (int i = threadIdx.x; i < polinl::H + 32; i += blockDim.x) s_b23[i] = m.staged[polinl::B2 + i];
     if (m.dev_lds)  // the geometry block, re-read every iteration (see k_step): from LDS it is not a memory round trip
         for (int i = threadIdx.x; i < (int)(sizeof(EcDev) / 16); i += blockDim.x)
@@ -2253,6 +2265,8 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
         }
         ec_dev_globalize(d, opaque);
         int64_t* act = actions0 + (int64_t)it * d.P;
+        // (see the Actor evaluation below) rows beyond a main wave's first 32 go to the producer waves
+        const bool split = (int)blockDim.x > d.nmain && (d.epw > 0 ? d.epw * d.N : 64) > 32;
 #ifdef EC_STAMPS
         dbg_out = d.stamps;
         const u64 dbg_t0 = wall_clock64();
@@ -2266,14 +2280,20 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
             const int32_t* av = it == 0 ? m.avail0 : next_avail0 + (int64_t)(it - 1) * d.P * d.A;
             const float* un = m.uniforms ? m.uniforms + (int64_t)it * d.P : nullptr;
             int pick = -1;
-            if ((int)threadIdx.x < d.nmain) {  // wave-uniform
-                const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-                const int64_t row_base = (int64_t)blockIdx.x * d.epb * d.N;  // the block's rows are contiguous (lane_id)
-                const int64_t left = d.P - row_base;
-                const int nrows = left < (int64_t)d.epb * d.N ? (int)left : d.epb * d.N;
-                const int per = d.epw > 0 ? d.epw * d.N : 64;  // rows of a main wave (lane_id_main)
+            const int64_t row_base = (int64_t)blockIdx.x * d.epb * d.N;  // the block's rows are contiguous (lane_id)
+            const int64_t left = d.P - row_base;
+            const int nrows = left < (int64_t)d.epb * d.N ? (int)left : d.epb * d.N;
+            const int per = d.epw > 0 ? d.epw * d.N : 64;  // rows of a main wave (lane_id_main)
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const int nmw = d.nmain >> 6, npw = ((int)blockDim.x - d.nmain) >> 6;
+            // With RNG producer waves in the block the rows of a main wave beyond its first 32 (one 32-row MFMA group
+            // is what a wave evaluates in one go) are the producer waves' job, at the same time on another SIMD; the
+            // actions reach their lanes through LDS behind the step's first barrier.  Same arithmetic per row either
+            // way (policy_rows<., 1> == one group of policy_rows<., 2>).
+            if (wave < nmw) {  // wave-uniform
                 const int r0 = wave * per;
-                const int cnt = nrows - r0 < per ? nrows - r0 : per;
+                int cnt = nrows - r0 < per ? nrows - r0 : per;
+                if (split && cnt > 32) cnt = 32;
                 if (cnt > 32) {
                     pick = d.A <= 16 ? polinl::policy_rows<2, 2>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane)
                                      : polinl::policy_rows<4, 2>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
@@ -2281,8 +2301,17 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
                     pick = d.A <= 16 ? polinl::policy_rows<2, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane)
                                      : polinl::policy_rows<4, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
                 }
+            } else if (split) {
+                for (int w = wave - nmw; w < nmw; w += npw) {  // the remainders of main waves w, w + npw, ...
+                    const int r0 = w * per + 32;
+                    const int cnt = nrows - r0 < per - 32 ? nrows - r0 : per - 32;
+                    if (cnt <= 0) continue;
+                    const int pk = d.A <= 16 ? polinl::policy_rows<2, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane)
+                                             : polinl::policy_rows<4, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
+                    if (lane < cnt) s_pick[r0 + lane] = pk;  // index = the taking lane's slot (lane_id_main: w * per + l)
+                }
             }
-            if (it > 0) cr.action = pick;  // the first step reads act[] (this lane's own store)
+            if (it > 0) cr.action = pick;  // the first step reads act[] (this lane's own store); split rows: s_pick
         }
 #ifdef EC_STAMPS
         const u64 dbg_t1 = wall_clock64();
@@ -2294,7 +2323,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
                                     counters0 ? counters0 + hs * d.B * 4 : nullptr,
                                     completion_time0 ? completion_time0 + hs * d.B : nullptr, next_obs0 + hs * d.P * 9,
                                     next_avail0 + hs * d.P * d.A, StepPolicy{0, 0, nullptr, m.n_steps, 1}, cr, it == 0,
-                                    it + 1 == m.n_steps);
+                                    it + 1 == m.n_steps, split ? s_pick : nullptr);
 #ifdef EC_STAMPS
         dbg_prev = wall_clock64();
         dbg_pol += dbg_t1 - dbg_t0;
@@ -2874,7 +2903,8 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     h->rollout_mlp = d.A <= 32 ? pick_rollout_mlp(d.k, D) : nullptr;
     h->d_staged = nullptr;
     if (h->rollout_mlp) {
-        h->lds_rollout_mlp = ((h->lds_step + 15) & ~(size_t)15) + (polinl::H + 32) * sizeof(float);  // + layer-2/3 biases
+        // + layer-2/3 biases + one action word per main lane (the producer waves' share of the Actor rows)
+        h->lds_rollout_mlp = ((h->lds_step + 15) & ~(size_t)15) + (polinl::H + 32) * sizeof(float) + (size_t)d.nmain * sizeof(int);
         if (h->lds_rollout_mlp > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_rollout_mlp);
         {   // + a copy of the geometry block, if that does not cost a resident block
             int with = 0, without = 0;
