@@ -53,7 +53,8 @@ constexpr u32 STAGED_FINAL = 0x80000000u;  // flag on the window's staged count:
 constexpr u32 STAGED_COUNT = 0xffu;        // RC_STAGED word: bits 0-7 draws staged, bits 8-23 "hot" flags of the first
 constexpr int STAGED_HOT_SHIFT = 8;        // RB_EARLY draws (see StepLds::hot), bit 31 STAGED_FINAL
 constexpr int AHEAD_MAX = 512;  // cap of the words kept regenerated ahead (a 64-word batch must not lap the cursor)
-constexpr int ACC_LDS = 256; // low part of the tick LUT kept in LDS
+constexpr int ACC_LDS = 256; // 8-byte words of LDS for the tick LUT: its first 4 * ACC_LDS entries (16-bit corrections)
+constexpr int ACC_LDS_N = 4 * ACC_LDS;
 
 // task record while in buffer_queue / new_task / a receiving queue (32 B)
 struct __attribute__((aligned(16))) Rec {
@@ -117,7 +118,9 @@ struct alignas(16) EcDev {
     double pen_drop, pen_fail, rew_succ, pen_hop;
     double obs_size_norm, obs_cyc_norm;
     // constant tables
-    const double* acc;        // [maxTicks+1]
+    const int16_t* acc;       // [>= max(maxTicks + 1, ACC_LDS_N), multiple of 4] tick LUT as corrections: the reference's
+                              //     timer after n additions of dt is the double whose bit pattern is
+                              //     bits(fl(n * dt)) + acc[n] (computed on the host from the same additions)
     const double* cap;        // [N]
     const u64* thr_exec_m;    // [N] floor(exp(-efr*dt) * 2^53)
     const u32* hot_thr;       // [N] lowest 27-bit first-word threshold of the node's failure tests (execution and every
@@ -240,33 +243,45 @@ __device__ __forceinline__ double ddiv(double a, double b) { return __ddiv_rn(a,
 
 __device__ __forceinline__ void flag(const EcDev& d, u32 bit) { atomicOr(d.status, bit); }
 
-// tick LUT: low entries from LDS (when s_acc != nullptr), the rest from global.  An index beyond the LUT is
-// clamped and remembered in `ovf` (reported through the status word by the caller).
-typedef const double __attribute__((address_space(3))) * lds_cdouble_ptr;
+// tick LUT.  A reference timer is dt added n times in fp64 (edge_node.py:216,250,254,316,319), which is not n * dt:
+// the roundings accumulate.  The LUT stores, per n, the (small) distance in units in the last place between the two:
+// 2 bytes per entry, so the whole table of an episode sits in LDS (2 KB for 1024 entries) and a lookup is one LDS
+// read, one fp64 multiply and one integer add -- no global memory and no LDS-or-global divergence inside the step.
+// Entries beyond ACC_LDS_N (longer episodes) come from global memory.  An index beyond the LUT is clamped and
+// remembered in `ovf` (reported through the status word by the caller).
+typedef const int16_t __attribute__((address_space(3))) * lds_ci16_ptr;
 struct Lut {
     const EcDev& d;
-    lds_cdouble_ptr s_acc;  // explicitly LDS: keeps the two loads below from being merged into one flat load
+    lds_ci16_ptr s_acc;  // explicitly LDS: keeps the two loads below from being merged into one flat load
     mutable u32 ovf;
+    __device__ __forceinline__ double make(u32 n, int corr) const {
+        return __longlong_as_double(__double_as_longlong(dmul((double)n, d.dt)) + (long long)corr);
+    }
     __device__ __forceinline__ double at(u32 n) const {
         ovf |= n > (u32)d.maxTicks ? 1u : 0u;
         n = n > (u32)d.maxTicks ? (u32)d.maxTicks : n;
-        if (n < (u32)ACC_LDS) return s_acc[n];
-        return d.acc[n];
+        int c;
+        if (n < (u32)ACC_LDS_N) c = s_acc[n];
+        else c = d.acc[n];
+        return make(n, c);
     }
     // acc[n .. n+3] (indices clamped to the LUT) with the four loads in flight together: the searches below
-    // advance four candidates per memory round trip instead of one
+    // advance four candidates per round trip instead of one
     __device__ __forceinline__ void peek4(u32 n, double (&a)[4]) const {
         const u32 mx = (u32)d.maxTicks;
         u32 i[4];
+        int c[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) i[j] = n + j > mx ? mx : n + j;
-        if (i[3] < (u32)ACC_LDS) {
+        if (i[3] < (u32)ACC_LDS_N) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) a[j] = s_acc[i[j]];
+            for (int j = 0; j < 4; j++) c[j] = s_acc[i[j]];
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) a[j] = d.acc[i[j]];
+            for (int j = 0; j < 4; j++) c[j] = d.acc[i[j]];
         }
+#pragma unroll
+        for (int j = 0; j < 4; j++) a[j] = make(i[j], c[j]);
     }
     // smallest n with acc[n] >= x, T16_NEVER if none in the LUT
     __device__ __forceinline__ u32 ticks_to_reach(double x) const {
@@ -924,7 +939,7 @@ __global__ void k_observe(EcDev d, float* __restrict__ obs, int32_t* __restrict_
 
 // LDS carve-up of k_step; all per-lane arrays are [slot][NT], NT = active lanes of the block
 struct StepLds {
-    double* acc;     // [ACC_LDS]
+    u64* acc;        // [ACC_LDS] words = the first ACC_LDS_N entries of the tick LUT
     uint4* wqm;      // [capW][NT]
     double* wqe;     // [capW][NT]
     u64* exC;        // [KMAX][NT] {ewt, twt, ctt, bwt} of the executing tasks (kept for ec_debug_dump)
@@ -1052,7 +1067,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         unsigned char* p = smem;
         S.wqm = reinterpret_cast<uint4*>(p);     p += (size_t)NT * d.capW * 16;
         S.rqrec = reinterpret_cast<uint4*>(p);   p += (size_t)NT * DMAX * 32;
-        S.acc = reinterpret_cast<double*>(p);    p += sizeof(double) * ACC_LDS;
+        S.acc = reinterpret_cast<u64*>(p);       p += sizeof(u64) * ACC_LDS;
         S.wqe = reinterpret_cast<double*>(p);    p += (size_t)NT * d.capW * 8;
         S.exC = reinterpret_cast<u64*>(p);       p += (size_t)NT * KMAX * 8;
         S.rew = reinterpret_cast<double*>(p);    p += (size_t)NT * 8;
@@ -1069,7 +1084,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         S.cnt = reinterpret_cast<u32*>(p);       p += (size_t)NT * 16;
         S.rc = reinterpret_cast<u32*>(p);        p += (size_t)NT * RC_N * 4;
     }
-    Lut lut{d, (lds_cdouble_ptr)S.acc, 0u};
+    Lut lut{d, (lds_ci16_ptr)S.acc, 0u};
 
     // Two roles.  The main lanes (threads < d.nmain) run the env logic and only CONSUME random words.  The RNG
     // producer lanes regenerate the Mersenne-Twister states and stage the step's draws: a wave of their own
@@ -1080,14 +1095,14 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
     const LaneId R = has_producers ? lane_id(d, d.nmain) : L;
     const bool producer_wave = has_producers ? (int)threadIdx.x >= d.nmain : true;  // wave-uniform
     const int tid = L.lidx;  // slot of this main lane in the per-lane LDS arrays
-    double lut_lo[ACC_LDS / 64];  // block-shared low part of the tick LUT: loaded by the producer lanes with their
+    u64 lut_lo[ACC_LDS / 64];  // block-shared LDS part of the tick LUT: loaded by the producer lanes with their
     if (producer_wave && first) { // first round of loads, stored to LDS before the first barrier
         const int p0 = has_producers ? (int)threadIdx.x - d.nmain : (int)threadIdx.x;
         const int np = has_producers ? (int)blockDim.x - d.nmain : (int)blockDim.x;
 #pragma unroll
         for (int i = 0; i < ACC_LDS / 64; i++) {
             const int a = p0 + i * np;
-            lut_lo[i] = d.acc[a <= d.maxTicks ? a : d.maxTicks];
+            lut_lo[i] = a < ACC_LDS ? reinterpret_cast<const u64*>(d.acc)[a] : 0ull;  // (the table is padded to ACC_LDS_N)
         }
     }
     const int64_t lane = L.lane;
@@ -2725,7 +2740,23 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     std::vector<double> efr(topo->efr, topo->efr + N), tfr(topo->tfr, topo->tfr + (size_t)N * N);
     std::vector<int> cores(topo->cores, topo->cores + N);
 
-    EC_TRY(dev_upload(h, &d.acc, acc));
+    {   // the tick LUT as 16-bit corrections to fl(n * dt) (see struct Lut)
+        size_t n_ent = (size_t)d.maxTicks + 1;
+        if (n_ent < (size_t)ACC_LDS_N) n_ent = ACC_LDS_N;
+        n_ent = (n_ent + 3) & ~(size_t)3;
+        std::vector<int16_t> corr(n_ent, 0);
+        for (int n = 0; n <= d.maxTicks; n++) {
+            const double prod = (double)n * cfg->mini_time_slot;
+            int64_t ba, bp;
+            memcpy(&ba, &acc[n], 8);
+            memcpy(&bp, &prod, 8);
+            const int64_t c = ba - bp;
+            if (c < -32768 || c > 32767)
+                return ec::fail(EC_EINVAL, "tick %d: accumulated timer is %lld ulp from n * mini_time_slot (16-bit table)", n, (long long)c);
+            corr[n] = (int16_t)c;
+        }
+        EC_TRY(dev_upload(h, &d.acc, corr));
+    }
     EC_TRY(dev_upload(h, &d.cap, cap));
     EC_TRY(dev_upload(h, &d.thr_exec_m, thr_exec_m));
     {   // lowest first-word threshold (M >> 26) among a node's failure tests: below it a draw fails none of them
