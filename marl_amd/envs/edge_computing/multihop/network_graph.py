@@ -73,6 +73,41 @@ def synthetic_edges(n, rng=None):
     return edges
 
 
+def graphml_edges(path):
+    """Edge list of a real-world topology file as generate_graph2 takes it (network_graph.py:267-307):
+    `[(int(u), int(v)) for u, v in nx.read_graphml(path).edges()]`, without networkx.  Returns (n_nodes, edges).
+
+    networkx adds the file's nodes in document order, then its edges in document order, and `Graph.edges()` walks the
+    nodes in that order and each node's neighbours in insertion order, reporting an edge at the first endpoint it
+    reaches: the edge ORDER decides which link draws (RandomState(link_seed), two per edge and pass) an edge gets, so
+    it is reproduced here.  A file with parallel edges is a MultiGraph to networkx, whose edges() repeats them."""
+    import xml.etree.ElementTree as ET
+    root = ET.parse(path).getroot()
+    ns = root.tag[:root.tag.index("}") + 1] if root.tag.startswith("{") else ""
+    graph = root.find(ns + "graph")
+    if graph is None:
+        raise ValueError("%s: no <graph> element" % path)
+    if graph.get("edgedefault", "undirected") == "directed":
+        raise ValueError("%s: directed topologies are not what generate_graph2 reads (it int()s an undirected edge list)" % path)
+    adj = {}  # node id -> {neighbour id: multiplicity}, both in insertion order
+    for node in graph.findall(ns + "node"):
+        adj.setdefault(node.get("id"), {})
+    for e in graph.findall(ns + "edge"):
+        u, v = e.get("source"), e.get("target")
+        adj.setdefault(u, {})
+        adj.setdefault(v, {})
+        adj[u][v] = adj[u].get(v, 0) + 1
+        if u != v:
+            adj[v][u] = adj[v].get(u, 0) + 1
+    edges, seen = [], set()
+    for u, nbrs in adj.items():
+        for v, mult in nbrs.items():
+            if v not in seen:
+                edges.extend([(int(u), int(v))] * mult)
+        seen.add(u)
+    return len(adj), edges
+
+
 def link_parameters(n_edges, args):
     """Two passes over RandomState(link_seed), each constructing a full Link (two uniforms) per edge and
     keeping one of its fields (network_graph.py:252-254, links.py:7-9)."""
@@ -90,6 +125,16 @@ def link_parameters(n_edges, args):
 
 def build_static_tables(args, edges=None):
     n = int(args.edge_node_num)
+    topo_file = getattr(args, "topology_file", "") or ""
+    if edges is None and topo_file:
+        # generate_graph2: a GraphML topology (the reference ships none; the path is absolute or relative to the cwd).
+        # As the reference notes (:293), edge_node_num must already be the file's node count.
+        n_file, edges = graphml_edges(topo_file)
+        if n_file != n:
+            raise ValueError("topology file %s has %d nodes, edge_node_num is %d" % (topo_file, n_file, n))
+        bad = [e for e in edges if not (0 <= e[0] < n and 0 <= e[1] < n)]
+        if bad:
+            raise ValueError("topology file %s: node ids must be 0..%d, got edge %s" % (topo_file, n - 1, bad[0]))
     edges = list(edges) if edges is not None else synthetic_edges(n)
     rates, fails = link_parameters(len(edges), args)
 
@@ -134,7 +179,7 @@ def get_static_tables(args):
     """Per-process cache, like the reference's class-level `EdgeNode.graph` (edge_node.py:19-20,87-91): the
     topology is generated once.  Keyed by what determines it, so that a second configuration in the same
     process gets what a fresh reference process would have built."""
-    key = (int(args.edge_node_num), int(args.link_seed), int(args.edge_node_seed),
+    key = (getattr(args, "topology_file", "") or "", int(args.edge_node_num), int(args.link_seed), int(args.edge_node_seed),
            float(args.transmission_rate_min), float(args.transmission_rate_max),
            float(args.transmission_failure_rate_min), float(args.transmission_failure_rate_max),
            float(args.task_probability_min), float(args.task_probability_max),

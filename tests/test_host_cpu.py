@@ -60,6 +60,42 @@ def _small_args(B):
                      normalize_advantages=True, ec_force_device="cpu")
 
 
+def test_graphml_topology_matches_networkx(tmp_path):
+    """generate_graph2 (network_graph.py:267-307): the stdlib GraphML reader yields the edge list, in the order,
+    that `nx.read_graphml(path).edges()` yields (the order assigns the link draws), and build_static_tables turns it
+    into the tables the reference's Graph / EdgeNode would hold (two Link passes over RandomState(link_seed))."""
+    nx = pytest.importorskip("networkx")
+    from marl_amd.envs.edge_computing.multihop import network_graph as ng
+    g = nx.Graph()
+    g.add_nodes_from(str(i) for i in (0, 3, 1, 2, 4, 5, 6))     # document order != numeric order
+    for u, v in ((3, 0), (0, 1), (2, 1), (5, 6), (4, 0), (6, 2), (3, 5), (1, 4)):
+        g.add_edge(str(u), str(v), LinkLabel="x")
+    path = str(tmp_path / "topo.graphml")
+    nx.write_graphml(g, path)
+    want = [(int(u), int(v)) for u, v in nx.read_graphml(path).edges()]
+    n, edges = ng.graphml_edges(path)
+    assert n == 7 and edges == want
+    a = make_args(["--edge_node_num=7", "--topology_file=" + path])
+    t = ng.build_static_tables(a)
+    assert t.edges == want
+    # link parameters: pass 1 keeps the rates, pass 2 the failure rates, two uniforms per Link (links.py:7-9)
+    rs = np.random.RandomState(a.link_seed)
+    rates = []
+    for _ in want:
+        rates.append(rs.uniform(a.transmission_rate_min, a.transmission_rate_max) * 1000000 * 8)
+        rs.uniform(a.transmission_failure_rate_min, a.transmission_failure_rate_max)
+    fails = []
+    for _ in want:
+        rs.uniform(a.transmission_rate_min, a.transmission_rate_max)
+        fails.append(rs.uniform(a.transmission_failure_rate_min, a.transmission_failure_rate_max))
+    for (u, v), r, f in zip(want, rates, fails):
+        assert t.rate[u, v] == t.rate[v, u] == r and t.tfr[u, v] == t.tfr[v, u] == f
+        assert t.adj[u, v] == t.adj[v, u] == 1
+    assert int(t.adj[:, :7].sum()) == 2 * len(want) + 7 and not t.adj[:, 7].any()
+    with pytest.raises(ValueError):
+        ng.build_static_tables(make_args(["--edge_node_num=9", "--topology_file=" + path]))
+
+
 def test_episode_buffer_cpu():
     from marl_amd.buffer.episode_buffer import EpisodeBuffer
     a = _small_args(5)
