@@ -310,6 +310,28 @@ int ec_ppo_critic_grad(const float* w1, const float* b1, const float* w2, const 
                        int32_t n_agents, int32_t hidden, float inv_denom, float* grads, float* loss, float* values,
                        void* stream);
 
+/* The same two launches for the minibatch updates of DGAILAgent._update_policy (rl/policy_gradient_rl/dgail/
+ * dgail_agent.py:283-325), which differ from PPOAgent.train in four ways the extra arguments cover:
+ *   row_index [rows] i64 or NULL: row r of the pass is row row_index[r] of the per-row tables (obs, avail, actions,
+ *       old_logp, adv, target, mask) -- a minibatch of the DataLoader's shuffle without gathering it first; the agent
+ *       id of a row is (table row) % n_agents; logp / entropy / values are indexed by r.
+ *   avail NULL: no action mask (dgail_agent.py:297 evaluates unmasked logits);  mask NULL: all ones.
+ *   flags & EC_PPO_LOGITS: torch's Categorical(logits=...) (:298-300): the exact log-softmax for log-prob and
+ *       entropy, without Categorical(probs=...)'s [eps, 1-eps] clamp.
+ *   critic n_agents = 0: the network reads the raw 9 observation inputs (ValueNet, dgail_network.py:22-34), w1 [64,9].
+ * With row_index NULL, flags 0 and avail / mask given they are ec_ppo_actor_grad / ec_ppo_critic_grad. */
+#define EC_PPO_LOGITS 1
+int ec_ppo_actor_grad_ex(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                         const float* b3, const float* obs, const int32_t* avail, const int64_t* actions,
+                         const float* old_logp, const float* adv, const float* mask, int64_t rows, int32_t n_agents,
+                         int32_t n_actions, int32_t hidden, float eps_clip, float entropy_coef, float inv_denom,
+                         float* grads, float* loss, float* logp, float* entropy, const int64_t* row_index, int32_t flags,
+                         void* stream);
+int ec_ppo_critic_grad_ex(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                          const float* b3, const float* obs, const float* target, const float* mask, int64_t rows,
+                          int32_t n_agents, int32_t hidden, float inv_denom, float* grads, float* loss, float* values,
+                          const int64_t* row_index, void* stream);
+
 const char* ec_last_error(void);
 const char* ec_version(void);
 

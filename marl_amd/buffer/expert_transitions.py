@@ -68,8 +68,14 @@ class ExpertTransitions:
         return self.obs[:size].reshape(size * N, -1)[idx], self.actions[:size].reshape(-1)[idx]
 
     def state_dict(self):
+        """The reference's expert_data.th layout (gail_agent.py:244-248): two Python lists of per-step CPU tensors
+        (obs [N,O], actions [N]), oldest first, so that the reference's GAILAgent.load_models can take the file and go on
+        appending / popping (:77-83).  The ring is unrolled from its oldest slot."""
         size = len(self)
-        return {"expert_obs": self.obs[:size].cpu(), "expert_actions": self.actions[:size].cpu()}
+        start = int(self._written.item()) % self.capacity if size == self.capacity else 0
+        order = (th.arange(size, device=self.device) + start) % max(size, 1)
+        obs, act = self.obs[order].cpu(), self.actions[order].cpu()
+        return {"expert_obs": list(obs.unbind(0)), "expert_actions": list(act.unbind(0))}
 
     def load_state_dict(self, sd):
         obs, act = sd["expert_obs"], sd["expert_actions"]

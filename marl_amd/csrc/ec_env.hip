@@ -2632,6 +2632,28 @@ void free_all(ec_env* h) {
     h->allocs.clear();
 }
 
+// Every entry point that takes a handle runs on the handle's device and leaves the caller's current device as it
+// found it (a handle built for cuda:1 may be driven from a thread whose current device is cuda:0).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define EC_ON_DEVICE(h)                                                                         \
+    DeviceGuard guard_((h)->device);                                                            \
+    if (guard_.err != hipSuccess)                                                               \
+        return ec::fail(EC_EHIP, "cannot switch to device %d: %s", (h)->device, hipGetErrorString(guard_.err))
+
 #define EC_TRY(expr)          \
     do {                      \
         int rc_ = (expr);     \
@@ -2991,11 +3013,15 @@ int ec_create(const ec_config* cfg, const ec_topology* topo, int64_t n_envs, int
     if (cfg->task_seed < 0 || cfg->failure_seed < 0 || env_id_base < 0 || cfg->task_seed + top > 0xFFFFFFFFll ||
         cfg->failure_seed + top > 0xFFFFFFFFll)
         return ec::fail(EC_EINVAL, "seed out of RandomState range");
-    EC_HIP(hipSetDevice(device));
     ec_env* h = new ec_env();
     memset(&h->d, 0, sizeof(h->d));
     h->device = device;
     h->state_bytes = 0;
+    DeviceGuard guard(device);  // the caller's current device is restored on return
+    if (guard.err != hipSuccess) {
+        delete h;
+        return ec::fail(EC_EHIP, "cannot switch to device %d: %s", device, hipGetErrorString(guard.err));
+    }
     int rc = build(h, cfg, topo, n_envs, env_id_base);
     if (rc) {
         free_all(h);
@@ -3008,7 +3034,7 @@ int ec_create(const ec_config* cfg, const ec_topology* topo, int64_t n_envs, int
 
 int ec_destroy(ec_handle h) {
     if (!h) return EC_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     (void)hipDeviceSynchronize();
     free_all(h);
     delete h;
@@ -3017,6 +3043,7 @@ int ec_destroy(ec_handle h) {
 
 int ec_reset(ec_handle h, void* stream) {
     if (!h) return ec::fail(EC_EINVAL, "null handle");
+    EC_ON_DEVICE(h);
     const int64_t gb = (h->d.P + 255) / 256;
     hipLaunchKernelGGL(k_reset, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, h->d);
     EC_HIP(hipGetLastError());
@@ -3026,6 +3053,7 @@ int ec_reset(ec_handle h, void* stream) {
 int ec_observe(ec_handle h, float* obs, int32_t* avail, void* stream) {
     if (!h) return ec::fail(EC_EINVAL, "null handle");
     if (!obs && !avail) return EC_OK;
+    EC_ON_DEVICE(h);
     hipLaunchKernelGGL(k_observe, dim3((unsigned)h->blocks), dim3(h->threads_obs), h->lds_obs, (hipStream_t)stream, h->d,
                        obs, avail);
     EC_HIP(hipGetLastError());
@@ -3036,6 +3064,7 @@ static int step_impl(ec_handle h, const int64_t* actions, float* reward, uint8_t
                      float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail, StepPolicy pol,
                      void* stream) {
     if (!h || !actions) return ec::fail(EC_EINVAL, "null handle or actions");
+    EC_ON_DEVICE(h);
     const bool multi = pol.n_steps > 1;
     pol.dev_lds = multi ? h->multi_dev_lds : 0;
     hipLaunchKernelGGL(multi ? h->step_multi : h->step, dim3((unsigned)h->blocks), dim3(h->threads),
@@ -3089,6 +3118,7 @@ int ec_rollout_mlp_policy(ec_handle h, int32_t n_steps, const float* w1, const f
     if (!h->rollout_mlp)
         return ec::fail(EC_EINVAL, "ec_rollout_mlp_policy is compiled for k <= 4, in-degree <= 8, n_actions <= 32 (have k=%d, A=%d)",
                         h->d.k, h->d.A);
+    EC_ON_DEVICE(h);
     const int rc = ec::stage_policy(w1, b1, w2, b2, w3, b3, h->d.N, h->d.A, h->d_staged, (hipStream_t)stream);
     if (rc != EC_OK) return rc;
     hipLaunchKernelGGL(h->rollout_mlp, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_rollout_mlp, (hipStream_t)stream,
@@ -3116,7 +3146,7 @@ int ec_random_policy(const int32_t* avail, int64_t rows, int32_t n_actions, uint
 
 int ec_expert_policy(ec_handle h, const int32_t* avail, int64_t* actions, void* stream) {
     if (!h || !avail || !actions) return ec::fail(EC_EINVAL, "ec_expert_policy: null argument");
-    EC_HIP(hipSetDevice(h->device));
+    EC_ON_DEVICE(h);
     hipLaunchKernelGGL(k_expert, dim3((unsigned)((h->d.P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->d, avail,
                        actions);
     EC_HIP(hipGetLastError());
@@ -3125,6 +3155,7 @@ int ec_expert_policy(ec_handle h, const int32_t* avail, int64_t* actions, void* 
 
 int ec_status(ec_handle h, uint32_t* status_host, int clear, void* stream) {
     if (!h || !status_host) return ec::fail(EC_EINVAL, "null argument");
+    EC_ON_DEVICE(h);
     EC_HIP(hipMemcpyAsync(status_host, h->d.status, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     if (clear) EC_HIP(hipMemsetAsync(h->d.status, 0, sizeof(uint32_t), (hipStream_t)stream));
     EC_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -3133,6 +3164,7 @@ int ec_status(ec_handle h, uint32_t* status_host, int clear, void* stream) {
 
 int ec_debug_dump(ec_handle h, int64_t env, double* rows_host, int64_t max_rows, int64_t* n_rows_host) {
     if (!h || !rows_host || !n_rows_host || env < 0 || env >= h->d.B) return ec::fail(EC_EINVAL, "bad argument");
+    EC_ON_DEVICE(h);
     double* rows = nullptr;
     int64_t* n = nullptr;
     EC_HIP(hipDeviceSynchronize());
@@ -3153,6 +3185,7 @@ int ec_debug_dump(ec_handle h, int64_t env, double* rows_host, int64_t max_rows,
 
 int ec_debug_rng_cursors(ec_handle h, uint64_t* cursors_host) {
     if (!h || !cursors_host) return ec::fail(EC_EINVAL, "null argument");
+    EC_ON_DEVICE(h);
     const size_t P = (size_t)h->d.P;
     std::vector<u64> tmp(2 * P);
     EC_HIP(hipDeviceSynchronize());
@@ -3166,6 +3199,7 @@ int ec_debug_rng_cursors(ec_handle h, uint64_t* cursors_host) {
 
 int ec_debug_live_tasks(ec_handle h, int64_t* total_host) {
     if (!h || !total_host) return ec::fail(EC_EINVAL, "null argument");
+    EC_ON_DEVICE(h);
     const size_t P = (size_t)h->d.P;
     std::vector<u32> tmp(P * (size_t)(4 + h->d.D));
     EC_HIP(hipDeviceSynchronize());

@@ -128,6 +128,10 @@ struct PpoArgs {
     float* loss;      // [1] accumulated into
     float* out_a;     // actor: log-prob of the taken action [R]; critic: value [R]
     float* out_b;     // actor: entropy [R]
+    // ec_ppo_*_grad_ex: row r of the pass is row row_index[r] of the per-row tables (a minibatch of a shuffled epoch);
+    // NULL: the identity.  Outputs (out_a / out_b) are indexed by r.
+    const int64_t* row_index;
+    int flags;        // EC_PPO_LOGITS: Categorical(logits=...) semantics (exact log-softmax, no [eps, 1-eps] clamp)
 };
 
 // HEAD 0: actor (TO3 output tiles), HEAD 1: critic.  IN1T: tiles of the first layer's dense input (9 + n_agents).
@@ -207,21 +211,36 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
         const int64_t rowbase = tile * 32;
         const int64_t row = rowbase + jrow;
         const bool ok = row < p.R;
+        const int64_t trow = ok ? (p.row_index ? p.row_index[row] : row) : 0;  // row of the per-row tables
         wave_sync();
         {
             const int64_t nvalid = (p.R - rowbase < 32 ? p.R - rowbase : 32);
-            for (int i = lane; i < 32 * OBS; i += 64) s_obs[i] = i < nvalid * OBS ? p.obs[rowbase * OBS + i] : 0.0f;
-            if (HEAD == 0)
-                for (int i = lane; i < 32 * A; i += 64) s_av[i] = i < nvalid * A ? p.avail[rowbase * A + i] : 0;
+            if (p.row_index) {
+                for (int i = lane; i < 32 * OBS; i += 64) {  // (source lanes r <= 31 are active in every trip, the last included)
+                    const int r = i / OBS;
+                    const int64_t src = __shfl((long long)trow, r);
+                    s_obs[i] = r < nvalid ? p.obs[src * OBS + (i - r * OBS)] : 0.0f;
+                }
+                if (HEAD == 0 && p.avail)
+                    for (int i0 = 0; i0 < 32 * A; i0 += 64) {
+                        const int i = i0 + lane, r = i < 32 * A ? i / A : 0;
+                        const int64_t src = __shfl((long long)trow, r);
+                        if (i < 32 * A) s_av[i] = r < nvalid ? p.avail[src * A + (i - r * A)] : 0;
+                    }
+            } else {
+                for (int i = lane; i < 32 * OBS; i += 64) s_obs[i] = i < nvalid * OBS ? p.obs[rowbase * OBS + i] : 0.0f;
+                if (HEAD == 0 && p.avail)
+                    for (int i = lane; i < 32 * A; i += 64) s_av[i] = i < nvalid * A ? p.avail[rowbase * A + i] : 0;
+            }
         }
         wave_sync();
-        const int agent = ok ? (int)(row % N) : 0;  // one-hot agent id (ppo_agent.py:64-65)
-        const float m = ok ? p.mask[row] : 0.0f;
+        const int agent = (ok && N > 0) ? (int)(trow % N) : 0;  // one-hot agent id (ppo_agent.py:64-65); N = 0: none
+        const float m = ok ? (p.mask ? p.mask[trow] : 1.0f) : 0.0f;
 
         // ------------------------------------------------------------------ forward
         f32x16 h1[2], h2[2];
         acc_init<2>(h1, s_b1, half);
-        acc_add<2>(h1, s_id + agent * H, half);
+        if (N > 0) acc_add<2>(h1, s_id + agent * H, half);
         acc_init<2>(h2, s_b2, half);
         chain_obs(h1, s_f1, s_obs, lane);
         chain<2, 2>(h2, s_f2, h1, lane, [](int, int, float x) { return relu(x); });
@@ -232,7 +251,8 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             acc_init<T3>(z, s_b3, half);
             chain<T3, 2>(z, s_f3, h2, lane, [](int, int, float x) { return relu(x); });
             // ---- head: masked softmax, Categorical log-prob / entropy, clipped surrogate (ppo_agent.py:76-83,135-141)
-            const int act = ok ? (int)p.actions[row] : 0;
+            const int act = ok ? (int)p.actions[trow] : 0;
+            const bool clampp = !(p.flags & EC_PPO_LOGITS);
             float mx = -3.0e38f;
 #pragma unroll
             for (int t = 0; t < T3; t++)
@@ -241,7 +261,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
                     const int j = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
                     float x = z[t][r];
                     if (j < A) {
-                        if (s_av[jrow * A + j] == 0) x = -1e10f;
+                        if (p.avail && s_av[jrow * A + j] == 0) x = -1e10f;
                         mx = fmaxf(mx, x);
                     }
                     z[t][r] = x;
@@ -267,8 +287,10 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
                 for (int r = 0; r < 16; r++) {
                     const int j = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
                     const float pj = z[t][r] * inv;
-                    const bool inr = pj >= EPS32 && pj <= 1.0f - EPS32;
-                    const float lp = logf(fminf(fmaxf(pj, EPS32), 1.0f - EPS32));
+                    // Categorical(probs): log of the clamped probability, zero gradient outside the clamp range;
+                    // Categorical(logits): the log-softmax itself (kept finite where a probability underflows)
+                    const bool inr = !clampp || (pj >= EPS32 && pj <= 1.0f - EPS32);
+                    const float lp = clampp ? logf(fminf(fmaxf(pj, EPS32), 1.0f - EPS32)) : fmaxf(logf(pj), -3.0e38f);
                     z[t][r] = pj;
                     const float g = j < A ? -(lp + (inr ? 1.0f : 0.0f)) : 0.0f;
                     gk[t][r] = g;
@@ -288,8 +310,8 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
                 if (p.out_b) p.out_b[row] = Hent;
             }
             if (!p.old_logp) continue;  // forward only
-            const float advr = ok ? p.adv[row] : 0.0f;
-            const float ratio = expf(lp_a - (ok ? p.old_logp[row] : 0.0f));
+            const float advr = ok ? p.adv[trow] : 0.0f;
+            const float ratio = expf(lp_a - (ok ? p.old_logp[trow] : 0.0f));
             const float lo = 1.0f - p.eps_clip, hi = 1.0f + p.eps_clip;
             const float surr1 = ratio * advr, surr2 = fminf(fmaxf(ratio, lo), hi) * advr;
             const float inrange = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
@@ -334,7 +356,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             const float v = part + __shfl_xor(part, 32) + s_b3[0];
             if (ok && half == 0 && p.out_a) p.out_a[row] = v;
             if (!p.target) continue;  // forward only
-            const float err = (v - (ok ? p.target[row] : 0.0f)) * m;
+            const float err = (v - (ok ? p.target[trow] : 0.0f)) * m;
             if (half == 0) loss_acc = fmaf(err * err, p.inv_denom, loss_acc);
             if (!backward) continue;
             const float dv = 2.0f * err * m * p.inv_denom;
@@ -377,7 +399,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
         wave_sync();
         put_tile<2>(Td, d1, lane, [](int, int, float x) { return x; });
         for (int in = half; in < 32 * IN1T; in += 2)
-            Ta[in * TS + jrow] = in < OBS ? s_obs[jrow * OBS + in] : ((ok && in - OBS == agent) ? 1.0f : 0.0f);
+            Ta[in * TS + jrow] = in < OBS ? s_obs[jrow * OBS + in] : ((ok && N > 0 && in - OBS == agent) ? 1.0f : 0.0f);
         wave_sync();
         wgrad<2, IN1T>(gW1, gb1, Td, Ta, lane);
     }
@@ -467,7 +489,7 @@ int check_common(const char* what, const void* const* ptrs, int n, int64_t rows,
         if (!ptrs[i]) return ec::fail(EC_EINVAL, "%s: null pointer", what);
     if (rows < 0) return ec::fail(EC_EINVAL, "%s: rows < 0", what);
     if (hidden != H) return ec::fail(EC_EINVAL, "%s: hidden_dim %d unsupported (this build: %d)", what, hidden, H);
-    if (n_agents < 1 || OBS + n_agents > 64) return ec::fail(EC_EINVAL, "%s: 9 + n_agents = %d exceeds 64", what, OBS + n_agents);
+    if (n_agents < 0 || OBS + n_agents > 64) return ec::fail(EC_EINVAL, "%s: 9 + n_agents = %d outside [9, 64]", what, OBS + n_agents);
     return EC_OK;
 }
 
@@ -475,19 +497,21 @@ int check_common(const char* what, const void* const* ptrs, int n, int64_t rows,
 
 extern "C" {
 
-int ec_ppo_actor_grad(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
-                      const float* obs, const int32_t* avail, const int64_t* actions, const float* old_logp,
-                      const float* adv, const float* mask, int64_t rows, int32_t n_agents, int32_t n_actions,
-                      int32_t hidden, float eps_clip, float entropy_coef, float inv_denom, float* grads, float* loss,
-                      float* logp, float* entropy, void* stream) {
+int ec_ppo_actor_grad_ex(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                         const float* b3, const float* obs, const int32_t* avail, const int64_t* actions,
+                         const float* old_logp, const float* adv, const float* mask, int64_t rows, int32_t n_agents,
+                         int32_t n_actions, int32_t hidden, float eps_clip, float entropy_coef, float inv_denom,
+                         float* grads, float* loss, float* logp, float* entropy, const int64_t* row_index, int32_t flags,
+                         void* stream) {
     if (rows == 0) return EC_OK;
-    const void* need[] = {w1, b1, w2, b2, w3, b3, obs, avail, actions, mask};
-    if (int rc = check_common("ec_ppo_actor_grad", need, 10, rows, hidden, n_agents)) return rc;
+    const void* need[] = {w1, b1, w2, b2, w3, b3, obs, actions};
+    if (int rc = check_common("ec_ppo_actor_grad", need, 8, rows, hidden, n_agents)) return rc;
+    if (n_agents < 1) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: n_agents %d", n_agents);
     if (n_actions < 1 || n_actions > 64) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: n_actions %d out of range [1,64]", n_actions);
     if (old_logp && !adv) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: old_logp without adv");
     if (grads && !old_logp) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: grads without old_logp");
     PpoArgs a{w1, b1, w2, b2, w3, b3, obs, avail, actions, old_logp, adv, nullptr, mask, rows, n_agents, n_actions,
-              eps_clip, entropy_coef, inv_denom, grads, loss, logp, entropy};
+              eps_clip, entropy_coef, inv_denom, grads, loss, logp, entropy, row_index, flags};
     const int TO3 = n_actions <= 32 ? 1 : 2, IN1T = OBS + n_agents <= 32 ? 1 : 2;
     if (TO3 == 1 && IN1T == 1) return launch_ppo<0, 1, 1>(a, (hipStream_t)stream);
     if (TO3 == 1) return launch_ppo<0, 1, 2>(a, (hipStream_t)stream);
@@ -495,17 +519,36 @@ int ec_ppo_actor_grad(const float* w1, const float* b1, const float* w2, const f
     return launch_ppo<0, 2, 2>(a, (hipStream_t)stream);
 }
 
+int ec_ppo_actor_grad(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                      const float* obs, const int32_t* avail, const int64_t* actions, const float* old_logp,
+                      const float* adv, const float* mask, int64_t rows, int32_t n_agents, int32_t n_actions,
+                      int32_t hidden, float eps_clip, float entropy_coef, float inv_denom, float* grads, float* loss,
+                      float* logp, float* entropy, void* stream) {
+    if (rows != 0 && (!avail || !mask)) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: null pointer");
+    return ec_ppo_actor_grad_ex(w1, b1, w2, b2, w3, b3, obs, avail, actions, old_logp, adv, mask, rows, n_agents, n_actions,
+                                hidden, eps_clip, entropy_coef, inv_denom, grads, loss, logp, entropy, nullptr, 0, stream);
+}
+
+int ec_ppo_critic_grad_ex(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                          const float* b3, const float* obs, const float* target, const float* mask, int64_t rows,
+                          int32_t n_agents, int32_t hidden, float inv_denom, float* grads, float* loss, float* values,
+                          const int64_t* row_index, void* stream) {
+    if (rows == 0) return EC_OK;
+    const void* need[] = {w1, b1, w2, b2, w3, b3, obs};
+    if (int rc = check_common("ec_ppo_critic_grad", need, 7, rows, hidden, n_agents)) return rc;
+    if (grads && !target) return ec::fail(EC_EINVAL, "ec_ppo_critic_grad: grads without target");
+    PpoArgs a{w1, b1, w2, b2, w3, b3, obs, nullptr, nullptr, nullptr, nullptr, target, mask, rows, n_agents, 1,
+              0.0f, 0.0f, inv_denom, grads, loss, values, nullptr, row_index, 0};
+    if (OBS + n_agents <= 32) return launch_ppo<1, 1, 1>(a, (hipStream_t)stream);
+    return launch_ppo<1, 1, 2>(a, (hipStream_t)stream);
+}
+
 int ec_ppo_critic_grad(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                        const float* obs, const float* target, const float* mask, int64_t rows, int32_t n_agents,
                        int32_t hidden, float inv_denom, float* grads, float* loss, float* values, void* stream) {
-    if (rows == 0) return EC_OK;
-    const void* need[] = {w1, b1, w2, b2, w3, b3, obs, mask};
-    if (int rc = check_common("ec_ppo_critic_grad", need, 8, rows, hidden, n_agents)) return rc;
-    if (grads && !target) return ec::fail(EC_EINVAL, "ec_ppo_critic_grad: grads without target");
-    PpoArgs a{w1, b1, w2, b2, w3, b3, obs, nullptr, nullptr, nullptr, nullptr, target, mask, rows, n_agents, 1,
-              0.0f, 0.0f, inv_denom, grads, loss, values, nullptr};
-    if (OBS + n_agents <= 32) return launch_ppo<1, 1, 1>(a, (hipStream_t)stream);
-    return launch_ppo<1, 1, 2>(a, (hipStream_t)stream);
+    if (rows != 0 && (!mask || n_agents < 1)) return ec::fail(EC_EINVAL, "ec_ppo_critic_grad: null mask or n_agents < 1");
+    return ec_ppo_critic_grad_ex(w1, b1, w2, b2, w3, b3, obs, target, mask, rows, n_agents, hidden, inv_denom, grads, loss,
+                                 values, nullptr, stream);
 }
 
 }  // extern "C"

@@ -27,10 +27,11 @@ from marl_amd.buffer.expert_transitions import ExpertTransitions
 from marl_amd.buffer.ppo_expert_buffer import PPOExpertBuffer
 from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import (DiffusionDiscriminator, GAILDiscriminator, PolicyNet,
                                                                 ValueNet)
-from marl_amd.utils import mlp_device
+from marl_amd.utils import mlp_device, ppo_device
 from marl_amd.utils.action_selectors import greedy_selector, soft_selector
 from marl_amd.utils.advantage_utils import get_gae
-from marl_amd.utils.dist_utils import all_reduce_grads_, broadcast_params_, dist_on, global_mean, global_mean_std
+from marl_amd.utils.dist_utils import (all_reduce_grads_, all_reduce_sum_, broadcast_params_, dist_on, global_mean,
+                                       global_mean_std, world_size)
 
 
 class DGAILAgent:
@@ -81,6 +82,15 @@ class DGAILAgent:
         self.min_bc_weight = getattr(args, "min_bc_weight", 0.05)
         self.performance_history = []
         self._eye = th.eye(self.n_agents, device=self.device)
+        # fused HIP minibatch update of policy / value (ec_ppo_*_grad_ex): every p.grad is a view into one flat buffer
+        # per network that the kernels accumulate into, the BC term's autograd adds to, and the DP all-reduce reduces
+        self._fg_policy = self._fg_value = None
+        if self._fused_ok() and not getattr(args, "ec_torch_update", False):
+            self._fg_policy = ppo_device.FlatGrads(self.policy)
+            self._fg_value = ppo_device.FlatGrads(self.value)
+        elif self.device.type == "cuda":
+            print("DGAILAgent: hidden_dim=%s / obs_shape=%s / ec_torch_update: the policy/value update runs on torch "
+                  "autograd, not on the fused HIP kernels" % (args.hidden_dim, self.obs_shape))
 
     # ------------------------------------------------------------------ acting
     def _fused_ok(self):
@@ -260,6 +270,8 @@ class DGAILAgent:
         next_obs = batch["next_obs"]
         rewards = batch["rewards"]
         B, T, N = obs.shape[0], obs.shape[1], obs.shape[2]
+        if self._fg_policy is not None:
+            return self._update_policy_fused(obs, actions, masks, next_obs, rewards)
         policy_input = self._with_ids(obs).reshape(-1, self.policy_input_dim)
         with th.no_grad():
             values = self.value(obs.reshape(-1, self.obs_shape)).reshape(B, T, N, 1)
@@ -293,6 +305,120 @@ class DGAILAgent:
                     self._minibatch_step(policy_input, act_f, log_probs_old, adv_f, ret_f, idx, bc, bc_w, totals)
         totals = (totals / (a.ppo_epochs * n_mb)).tolist()
         return {"policy_loss": totals[0], "value_loss": totals[1], "entropy": totals[2]}
+
+    def _update_policy_fused(self, obs, actions, masks, next_obs, rewards):
+        """_update_policy on the fused kernels: the no-grad passes (values, old log-probs) and every minibatch step's
+        forward + loss + backward of both networks are ec_ppo_actor_grad_ex / ec_ppo_critic_grad_ex launches that read
+        their minibatch through the epoch's permutation (no gathered copies, no autograd graph); the BC term's small
+        autograd backward adds into the same flat gradient buffer.  One hipGraph per step when single-process."""
+        a = self.args
+        B, T, N = obs.shape[0], obs.shape[1], obs.shape[2]
+        self._fg_policy.bind()  # (the BC pretrain's zero_grad() drops the .grad tensors)
+        self._fg_value.bind()
+        obs_f = obs.reshape(-1, self.obs_shape)
+        act_f = actions.reshape(-1)
+        values = ppo_device.critic_pass(self.value, obs_f, None, 0, want_values=True).view(B, T, N, 1)
+        next_values = ppo_device.critic_pass(self.value, next_obs.reshape(-1, self.obs_shape), None, 0,
+                                             want_values=True).view(B, T, N, 1)
+        advantages = get_gae(a, rewards, values, next_values, masks)
+        ret_f = (advantages + values).reshape(-1)
+        mean, std = global_mean_std(advantages)
+        adv_f = ((advantages - mean) / (std + 1e-8)).reshape(-1)
+        logp_old, _ = ppo_device.actor_pass(self.policy, obs_f, None, act_f, None, N, want_logp=True, logits=True)
+        rows = act_f.shape[0]
+        mb = max(1, int(a.ppo_batch_size) * int(getattr(a, "n_threads", 1)))
+        n_mb = (rows + mb - 1) // mb
+        bc_w = th.full((), float(self.bc_loss_weight), device=self.device)
+        tables = (obs_f, act_f, logp_old, adv_f, ret_f)
+        graph = self._fused_graph(tables, mb, bc_w) if (self._graph_update and rows >= mb) else None
+        totals = graph["totals"] if graph is not None else th.zeros(3, device=self.device)
+        for _ in range(a.ppo_epochs):
+            perm = self.rng.permutation(rows)
+            for i in range(n_mb):
+                idx = perm[i * mb:(i + 1) * mb]
+                bc = self.expert_transitions.sample_transitions(a.batch_expert_transitions)
+                if graph is not None and idx.shape[0] == mb and bc[1].shape == graph["bc_act"].shape:
+                    graph["idx"].copy_(idx)
+                    graph["bc_obs"].copy_(bc[0])
+                    graph["bc_act"].copy_(bc[1])
+                    graph["graph"].replay()
+                else:
+                    self._fused_step(tables, idx.contiguous(), bc, bc_w, totals)
+        totals = (totals / (a.ppo_epochs * n_mb)).tolist()
+        return {"policy_loss": totals[0], "value_loss": totals[1], "entropy": totals[2]}
+
+    def _fused_step(self, tables, idx, bc, bc_w, totals):
+        """dgail_agent.py:283-325 for the rows `idx`: loss = policy - c_H * H + c_V * value + w_bc * BC, clipped Adam
+        steps of both networks; no host synchronisation (capturable)."""
+        a = self.args
+        obs_f, act_f, logp_old, adv_f, ret_f = tables
+        n = idx.shape[0]
+        losses = th.zeros(2, device=self.device)
+        self._fg_policy.zero_()
+        self._fg_value.zero_()
+        ws = world_size()
+        # (under data parallelism every rank's share enters with weight 1 / world: the summed gradient is the mean)
+        _, ent = ppo_device.actor_pass(self.policy, obs_f, None, act_f, None, self.n_agents, old_logp=logp_old, adv=adv_f,
+                                       eps_clip=a.clip_param, entropy_coef=a.entropy_coef, inv_denom=1.0 / (n * ws),
+                                       grads=self._fg_policy.flat, loss=losses[0:1], want_entropy=True, row_index=idx,
+                                       logits=True)
+        ppo_device.critic_pass(self.value, obs_f, None, 0, target=ret_f, inv_denom=a.value_loss_coef / (n * ws),
+                               grads=self._fg_value.flat, loss=losses[1:2], row_index=idx)
+        (bc_w * self._compute_bc_loss(bc) / ws).backward()   # adds into the policy's flat gradient
+        all_reduce_sum_(self._fg_policy.flat)
+        all_reduce_sum_(self._fg_value.flat)
+        th.nn.utils.clip_grad_norm_(self.policy.parameters(), a.grad_norm_clip)
+        th.nn.utils.clip_grad_norm_(self.value.parameters(), a.grad_norm_clip)
+        self.policy_optimizer.step()
+        self.value_optimizer.step()
+        ent_mean = ent.mean()
+        # the kernel's actor loss is policy_loss - c_H * entropy; the reference reports the three terms separately
+        totals += th.stack([losses[0] * ws + a.entropy_coef * ent_mean, losses[1] * ws / a.value_loss_coef, ent_mean])
+
+    def _fused_graph(self, tables, mb, bc_w):
+        """Static copies of the iteration's per-row tables and one captured _fused_step over them (see
+        _minibatch_graph: same scheme for the fused kernels)."""
+        n_bc = min(int(self.args.batch_expert_transitions), len(self.expert_transitions))
+        key = ("fused", tuple(tables[0].shape), mb, n_bc)
+        g = self._mb_graph
+        if g is None or g["key"] != key:
+            dev = self.device
+            g = {"key": key, "tables": tuple(th.empty_like(t) for t in tables),
+                 "idx": th.zeros(mb, dtype=th.long, device=dev),
+                 "bc_obs": th.zeros(n_bc, self.n_agents, self.obs_shape, device=dev),
+                 "bc_act": th.zeros(n_bc, self.n_agents, dtype=th.long, device=dev),
+                 "bc_w": th.zeros((), device=dev), "totals": th.zeros(3, device=dev), "graph": None}
+        for dst, src in zip(g["tables"], tables):
+            dst.copy_(src)
+        g["bc_w"].copy_(bc_w)
+        if g["graph"] is None:
+            rows = tables[1].shape[0]
+            snap = [copy.deepcopy(m.state_dict()) for m in (self.policy, self.value, self.policy_optimizer,
+                                                            self.value_optimizer)]
+            side = th.cuda.Stream(device=self.device)
+            side.wait_stream(th.cuda.current_stream(self.device))
+            with th.cuda.stream(side):
+                for _ in range(3):  # warm-up only, undone below: no draw is taken from self.rng for it
+                    idx = th.randint(0, rows, (mb,), device=self.device)
+                    bc = (self.expert_transitions.obs[:n_bc], self.expert_transitions.actions[:n_bc])
+                    self._fused_step(g["tables"], idx, bc, g["bc_w"], th.zeros(3, device=self.device))
+            th.cuda.current_stream(self.device).wait_stream(side)
+            th.cuda.synchronize(self.device)
+            for m, sd in zip((self.policy, self.value, self.policy_optimizer, self.value_optimizer), snap):
+                m.load_state_dict(sd)
+            for opt in (self.policy_optimizer, self.value_optimizer):
+                for group in opt.param_groups:
+                    for prm in group["params"]:
+                        if len(opt.state[prm]) == 0:
+                            opt.state[prm] = {"step": th.zeros((), dtype=th.float32, device=prm.device),
+                                              "exp_avg": th.zeros_like(prm), "exp_avg_sq": th.zeros_like(prm)}
+            graph = th.cuda.CUDAGraph()
+            with th.cuda.graph(graph):
+                self._fused_step(g["tables"], g["idx"], (g["bc_obs"], g["bc_act"]), g["bc_w"], g["totals"])
+            g["graph"] = graph
+            self._mb_graph = g
+        g["totals"].zero_()
+        return g
 
     def _minibatch_step(self, policy_input, act_f, log_probs_old, adv_f, ret_f, idx, bc, bc_w, totals):
         """One optimiser step of dgail_agent.py:283-325 on the rows `idx`; no host synchronisation (capturable)."""

@@ -149,6 +149,8 @@ class GAILAgent:
         (64 expert transitions) is back-propagated by autograd INTO the same flat gradient buffer."""
         a = self.args
         N = a.n_agents
+        self._fg_actor.bind()
+        self._fg_critic.bind()
         shape = rewards.shape
         if a.normalize_rewards:
             mean, std = global_mean_std(rewards)

@@ -93,6 +93,8 @@ class PPOAgent:
         ec_ppo_critic_grad): no autograd graph, no per-row intermediates in HBM."""
         a = self.args
         N = a.n_agents
+        self._fg_actor.bind()
+        self._fg_critic.bind()
         obs, avail_actions, actions, rewards, masks, next_obs = self.buffer.sample()
         shape = rewards.shape
         if a.normalize_rewards:

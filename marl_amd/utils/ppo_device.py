@@ -16,9 +16,16 @@ class FlatGrads:
         self.params = [p for p in module.parameters()]
         n = sum(p.numel() for p in self.params)
         self.flat = th.zeros(n, dtype=th.float32, device=self.params[0].device)
+        self.bind()
+
+    def bind(self):
+        """(re)point every p.grad into the flat buffer: an optimizer's zero_grad() (set_to_none) or a checkpoint load
+        in between replaces the .grad tensors, after which the kernels and the optimizer would use different memory"""
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            view = self.flat[off:off + p.numel()].view_as(p)
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                p.grad = view
             off += p.numel()
 
     def zero_(self):
@@ -30,45 +37,70 @@ def _rows(obs):
     return obs, obs.shape[0]
 
 
+EC_PPO_LOGITS = 1
+
+
+def _index(row_index, dev):
+    if row_index is None:
+        return None
+    if row_index.dtype != th.int64 or not row_index.is_contiguous() or row_index.device != dev:
+        row_index = row_index.to(device=dev, dtype=th.int64).contiguous()
+    return row_index
+
+
 def actor_pass(actor, obs, avail, actions, mask, n_agents, old_logp=None, adv=None, eps_clip=0.2, entropy_coef=0.0,
-               inv_denom=1.0, grads=None, loss=None, want_logp=False, want_entropy=False):
-    """One launch over all rows.  Forward only when old_logp is None (returns logp / entropy); with old_logp and adv it
-    accumulates the loss into `loss` [1] and, if `grads` (flat, parameter order) is given, the gradient into it."""
+               inv_denom=1.0, grads=None, loss=None, want_logp=False, want_entropy=False, row_index=None, logits=False):
+    """One launch.  Forward only when old_logp is None (returns logp / entropy); with old_logp and adv it accumulates
+    the loss into `loss` [1] and, if `grads` (flat, parameter order) is given, the gradient into it.
+    row_index [r] (optional): the pass takes rows row_index[0..r) of the per-row tables (a shuffled minibatch), outputs
+    are in pass order; avail / mask may be None (no action mask / all ones); logits=True: Categorical(logits=...)."""
     w1, b1, w2, b2, w3, b3 = linear_params(actor)
-    obs, rows = _rows(obs)
+    obs, table_rows = _rows(obs)
     dev = obs.device
     A = w3.shape[0]
-    avail = avail.to(th.int32).contiguous().reshape(-1, A)
+    if avail is not None:
+        avail = avail.to(th.int32).contiguous().reshape(-1, A)
     actions = actions.to(th.int64).contiguous().reshape(-1)
-    mask = _f32(mask, "mask").reshape(-1)
+    if mask is not None:
+        mask = _f32(mask, "mask").reshape(-1)
     if old_logp is not None:
         old_logp = _f32(old_logp, "old_logp").reshape(-1)
         adv = _f32(adv, "adv").reshape(-1)
     for t in (avail, actions, mask, old_logp, adv):
-        if t is not None and t.shape[0] != rows:
+        if t is not None and t.shape[0] != table_rows:
             raise ValueError("rows mismatch")
+    row_index = _index(row_index, dev)
+    rows = table_rows if row_index is None else int(row_index.shape[0])
     logp = th.empty(rows, dtype=th.float32, device=dev) if want_logp else None
     ent = th.empty(rows, dtype=th.float32, device=dev) if want_entropy else None
     with th.cuda.device(dev):
-        _abi.check(_abi.lib().ec_ppo_actor_grad(_p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(obs), _p(avail),
-                                                _p(actions), _p(old_logp), _p(adv), _p(mask), rows, int(n_agents),
-                                                int(A), int(w2.shape[0]), C.c_float(eps_clip),
-                                                C.c_float(entropy_coef), C.c_float(inv_denom), _p(grads), _p(loss),
-                                                _p(logp), _p(ent), _stream(dev)), "ec_ppo_actor_grad")
+        _abi.check(_abi.lib().ec_ppo_actor_grad_ex(_p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(obs), _p(avail),
+                                                   _p(actions), _p(old_logp), _p(adv), _p(mask), rows, int(n_agents),
+                                                   int(A), int(w2.shape[0]), C.c_float(eps_clip),
+                                                   C.c_float(entropy_coef), C.c_float(inv_denom), _p(grads), _p(loss),
+                                                   _p(logp), _p(ent), _p(row_index), EC_PPO_LOGITS if logits else 0,
+                                                   _stream(dev)), "ec_ppo_actor_grad_ex")
     return logp, ent
 
 
-def critic_pass(critic, obs, mask, n_agents, target=None, inv_denom=1.0, grads=None, loss=None, want_values=False):
+def critic_pass(critic, obs, mask, n_agents, target=None, inv_denom=1.0, grads=None, loss=None, want_values=False,
+                row_index=None):
+    """n_agents = 0: the network takes the 9 observation inputs only (DGAIL's ValueNet); row_index / mask as actor_pass."""
     w1, b1, w2, b2, w3, b3 = linear_params(critic)
-    obs, rows = _rows(obs)
+    obs, table_rows = _rows(obs)
     dev = obs.device
-    mask = _f32(mask, "mask").reshape(-1)
+    if w1.shape[1] != OBS_DIM + n_agents:
+        raise ValueError("critic input width %d is not 9 + %d" % (w1.shape[1], n_agents))
+    if mask is not None:
+        mask = _f32(mask, "mask").reshape(-1)
     if target is not None:
         target = _f32(target, "target").reshape(-1)
+    row_index = _index(row_index, dev)
+    rows = table_rows if row_index is None else int(row_index.shape[0])
     values = th.empty(rows, dtype=th.float32, device=dev) if want_values else None
     with th.cuda.device(dev):
-        _abi.check(_abi.lib().ec_ppo_critic_grad(_p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(obs), _p(target),
-                                                 _p(mask), rows, int(n_agents), int(w2.shape[0]),
-                                                 C.c_float(inv_denom), _p(grads), _p(loss), _p(values), _stream(dev)),
-                   "ec_ppo_critic_grad")
+        _abi.check(_abi.lib().ec_ppo_critic_grad_ex(_p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(obs), _p(target),
+                                                    _p(mask), rows, int(n_agents), int(w2.shape[0]),
+                                                    C.c_float(inv_denom), _p(grads), _p(loss), _p(values),
+                                                    _p(row_index), _stream(dev)), "ec_ppo_critic_grad_ex")
     return values

@@ -218,9 +218,15 @@ def test_expert_transitions_fifo():
     assert so.shape == (5, 2, 3) and sorted(sa[:, 0].tolist()) == [3, 10, 11, 12, 13]   # without replacement
     ro, ra = st.sample_rows(1000)
     assert ro.shape == (1000, 3) and set(ra.tolist()) <= {3, 10, 11, 12, 13}
+    # the checkpoint is the reference's expert_data.th layout (gail_agent.py:244-248): lists of per-step tensors,
+    # oldest first, although the ring has wrapped
+    sd = st.state_dict()
+    assert isinstance(sd["expert_obs"], list) and sd["expert_obs"][0].shape == (2, 3) and sd["expert_actions"][0].shape == (2,)
+    assert [int(x[0]) for x in sd["expert_actions"]] == [3, 10, 11, 12, 13]
+    assert all(int(o_[0, 0]) == int(a_[0]) for o_, a_ in zip(sd["expert_obs"], sd["expert_actions"]))
     st2 = ExpertTransitions(5, 2, 3, "cpu")
-    st2.load_state_dict(st.state_dict())
-    assert len(st2) == 5 and th.equal(st2.actions[:5], st.actions[:5])
+    st2.load_state_dict(sd)
+    assert len(st2) == 5 and st2.actions[:5, 0].tolist() == [3, 10, 11, 12, 13]
     st3 = ExpertTransitions(5, 2, 3, "cpu")                       # the reference's list-of-tensors checkpoint layout
     st3.load_state_dict({"expert_obs": [o[i] for i in range(4)], "expert_actions": [a[i] for i in range(4)]})
     assert len(st3) == 4
