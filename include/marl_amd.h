@@ -321,6 +321,9 @@ int ec_ppo_critic_grad(const float* w1, const float* b1, const float* w2, const 
  *   critic n_agents = 0: the network reads the raw 9 observation inputs (ValueNet, dgail_network.py:22-34), w1 [64,9].
  * With row_index NULL, flags 0 and avail / mask given they are ec_ppo_actor_grad / ec_ppo_critic_grad. */
 #define EC_PPO_LOGITS 1
+/* flags & EC_PPO_GATHERED: the per-row tables are already in pass order (the caller gathered the minibatch: coalesced
+ * reads instead of one random row per lane); row_index then only names each row's agent, (row_index[r]) % n_agents. */
+#define EC_PPO_GATHERED 2
 int ec_ppo_actor_grad_ex(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                          const float* b3, const float* obs, const int32_t* avail, const int64_t* actions,
                          const float* old_logp, const float* adv, const float* mask, int64_t rows, int32_t n_agents,

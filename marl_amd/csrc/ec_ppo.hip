@@ -18,6 +18,8 @@
 //                a per-wave LDS tile ([index][row], stride 33) and accumulated in persistent MFMA accumulators; bias
 //                gradients ride along as a per-lane running sum of the A operand.  One atomic add per accumulator
 //                register at the end of the wave's row loop.
+#include <cstdlib>
+
 #include "ec_mfma.h"
 
 namespace {
@@ -211,11 +213,13 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
         const int64_t rowbase = tile * 32;
         const int64_t row = rowbase + jrow;
         const bool ok = row < p.R;
-        const int64_t trow = ok ? (p.row_index ? p.row_index[row] : row) : 0;  // row of the per-row tables
+        const bool gathered = (p.flags & EC_PPO_GATHERED) != 0;  // tables already in pass order: the index only names the agent
+        const int64_t irow = ok ? (p.row_index ? p.row_index[row] : row) : 0;
+        const int64_t trow = gathered ? (ok ? row : 0) : irow;  // row of the per-row tables
         wave_sync();
         {
             const int64_t nvalid = (p.R - rowbase < 32 ? p.R - rowbase : 32);
-            if (p.row_index) {
+            if (p.row_index && !gathered) {
                 for (int i = lane; i < 32 * OBS; i += 64) {  // (source lanes r <= 31 are active in every trip, the last included)
                     const int r = i / OBS;
                     const int64_t src = __shfl((long long)trow, r);
@@ -234,7 +238,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             }
         }
         wave_sync();
-        const int agent = (ok && N > 0) ? (int)(trow % N) : 0;  // one-hot agent id (ppo_agent.py:64-65); N = 0: none
+        const int agent = (ok && N > 0) ? (int)(irow % N) : 0;  // one-hot agent id (ppo_agent.py:64-65); N = 0: none
         const float m = ok ? (p.mask ? p.mask[trow] : 1.0f) : 0.0f;
 
         // ------------------------------------------------------------------ forward
@@ -473,6 +477,12 @@ int launch_ppo(const PpoArgs& a, hipStream_t stream) {
         EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ppo<HEAD, TO3, IN1T, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (blocks > 256) blocks = 256;  // one block per CU: the row loop amortises weight staging and the final atomics
+        // a minibatch-sized pass (DGAIL: 64 steps of 262 k rows per iteration) is dominated by those fixed costs, every
+        // wave ending with ~150 atomic instructions onto the same 6 k gradient words: at least PPO_MIN_TILES row tiles
+        // per wave before another block is worth its flush
+        static const int min_tiles = getenv("MARL_AMD_PPO_MIN_TILES") ? atoi(getenv("MARL_AMD_PPO_MIN_TILES")) : 16;
+        const int64_t want = (tiles + (int64_t)nw * min_tiles - 1) / ((int64_t)nw * min_tiles);
+        if (blocks > want) blocks = want < 1 ? 1 : want;
         hipLaunchKernelGGL((k_ppo<HEAD, TO3, IN1T, true>), dim3((unsigned)blocks), dim3(64 * nw), lds, stream, a);
     } else {
         EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ppo<HEAD, TO3, IN1T, false>),

@@ -38,6 +38,7 @@ def _rows(obs):
 
 
 EC_PPO_LOGITS = 1
+EC_PPO_GATHERED = 2
 
 
 def _index(row_index, dev):
@@ -49,11 +50,13 @@ def _index(row_index, dev):
 
 
 def actor_pass(actor, obs, avail, actions, mask, n_agents, old_logp=None, adv=None, eps_clip=0.2, entropy_coef=0.0,
-               inv_denom=1.0, grads=None, loss=None, want_logp=False, want_entropy=False, row_index=None, logits=False):
+               inv_denom=1.0, grads=None, loss=None, want_logp=False, want_entropy=False, row_index=None, logits=False,
+               gathered=False):
     """One launch.  Forward only when old_logp is None (returns logp / entropy); with old_logp and adv it accumulates
     the loss into `loss` [1] and, if `grads` (flat, parameter order) is given, the gradient into it.
     row_index [r] (optional): the pass takes rows row_index[0..r) of the per-row tables (a shuffled minibatch), outputs
-    are in pass order; avail / mask may be None (no action mask / all ones); logits=True: Categorical(logits=...)."""
+    are in pass order; avail / mask may be None (no action mask / all ones); logits=True: Categorical(logits=...).
+    gathered=True: the tables ARE the minibatch (gathered by the caller); row_index only names each row's agent."""
     w1, b1, w2, b2, w3, b3 = linear_params(actor)
     obs, table_rows = _rows(obs)
     dev = obs.device
@@ -70,7 +73,9 @@ def actor_pass(actor, obs, avail, actions, mask, n_agents, old_logp=None, adv=No
         if t is not None and t.shape[0] != table_rows:
             raise ValueError("rows mismatch")
     row_index = _index(row_index, dev)
-    rows = table_rows if row_index is None else int(row_index.shape[0])
+    rows = table_rows if (row_index is None or gathered) else int(row_index.shape[0])
+    if gathered and (row_index is None or row_index.shape[0] != table_rows):
+        raise ValueError("gathered tables need one index per row")
     logp = th.empty(rows, dtype=th.float32, device=dev) if want_logp else None
     ent = th.empty(rows, dtype=th.float32, device=dev) if want_entropy else None
     with th.cuda.device(dev):
@@ -78,7 +83,8 @@ def actor_pass(actor, obs, avail, actions, mask, n_agents, old_logp=None, adv=No
                                                    _p(actions), _p(old_logp), _p(adv), _p(mask), rows, int(n_agents),
                                                    int(A), int(w2.shape[0]), C.c_float(eps_clip),
                                                    C.c_float(entropy_coef), C.c_float(inv_denom), _p(grads), _p(loss),
-                                                   _p(logp), _p(ent), _p(row_index), EC_PPO_LOGITS if logits else 0,
+                                                   _p(logp), _p(ent), _p(row_index),
+                                                   (EC_PPO_LOGITS if logits else 0) | (EC_PPO_GATHERED if gathered else 0),
                                                    _stream(dev)), "ec_ppo_actor_grad_ex")
     return logp, ent
 
