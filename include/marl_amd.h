@@ -236,6 +236,23 @@ int ec_diffusion_reward(const float* w1, const float* b1, const float* w2, const
                         int32_t hidden, float r1_lambda, float* loss_expert, float* loss_agent, float* d_phi,
                         float* reward, void* stream);
 
+/* DGAIL diffusion-discriminator update, one compute_loss call (one condition c) with its backward: replaces
+ * DiffusionDiscriminator.compute_loss (dgail_network.py:82-108; the R1 term is an autograd.grad with create_graph=True
+ * there) and, through `coef`, the loss.backward() of DGAILAgent._update_discriminator (dgail_agent.py:203-243).
+ *   w1 [64][ld1] (effective weight; columns [0, 9+n_actions) are the x part), bias_t [2][64] = b1 + W1t E_time[t] +
+ *   W1c E_cond[c] for t = 0, 1, w2 [64][64] (effective), w3 [9+n_actions][64], w3sum [64] = column sums of w3;
+ *   t u8 [rows] and noise [rows, 9+n_actions] are the draws of dgail_network.py:90-91.
+ *   loss [rows] (optional) <- mean_d (eps - noise)^2 + r1_lambda |d sum(eps) / d x_t|^2
+ *   grads (optional, ACCUMULATED into; needs coef [rows] = d objective / d loss[r]):
+ *       [dW1x 64*(9+n_actions) | dbias_t[0]+dbias_t[1] 64 | dbias_t[1] 64 | dW2 64*64 | db2 64 | dW3 (9+n_actions)*64 |
+ *        db3 9+n_actions | dw3sum 64]
+ * The chain rule to the module's own parameters (spectral norm, embeddings) is the caller's: a few 64x64 operations.
+ * 9+n_actions <= 64 and, with grads, != 32 and != 64 (the backward uses one spare input column). */
+int ec_diffusion_grad(const float* w1, int32_t ld1, const float* bias_t, const float* w2, const float* b2, const float* w3,
+                      const float* b3, const float* w3sum, const float* obs, const int64_t* actions, const uint8_t* t,
+                      const float* noise, const float* coef, int64_t rows, int32_t n_actions, int32_t hidden,
+                      float r1_lambda, float* loss, float* grads, void* stream);
+
 /* --- rollout bookkeeping ----------------------------------------------------------------------------------------
  * One launch per env step instead of ~20 torch launches: replaces EpisodeBuffer.insert (buffer/episode_buffer.py:21-28)
  * with the team-reward broadcast and mask = 1 - terminated of parallel_episode_runner.py:101-102, and the running

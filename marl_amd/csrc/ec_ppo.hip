@@ -20,100 +20,11 @@
 //                register at the end of the wave's row loop.
 #include <cstdlib>
 
-#include "ec_mfma.h"
+#include "ec_mfma_grad.h"
 
 namespace {
 
 constexpr float EPS32 = 1.1920929e-07f;  // torch.finfo(float32).eps: Categorical clamps probs to [eps, 1-eps]
-constexpr int TS = 33;                   // row stride of the transposition tiles
-
-// out[to] += frag * f(in): TI input tiles of 16 accumulator registers (k order kperm), one group of 32 rows
-template <int TO, int TI, typename F>
-__device__ __forceinline__ void chain(f32x16 (&out)[TO], const float* __restrict__ frag, const f32x16 (&in)[TI], int lane, F f) {
-#pragma unroll
-    for (int s4 = 0; s4 < 4 * TI; s4++) {
-#pragma unroll
-        for (int to = 0; to < TO; to++) {
-            const float4 a = *reinterpret_cast<const float4*>(frag + ((s4 * TO + to) * 64 + lane) * 4);
-            const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int T = s4 >> 2, r = (s4 & 3) * 4 + c;
-                out[to] = MFMA(av[c], f(T, r, in[T][r]), out[to]);
-            }
-        }
-    }
-}
-
-// first layer over the 9 observation inputs of the wave's 32 rows (s_obs [32][9])
-__device__ __forceinline__ void chain_obs(f32x16 (&out)[2], const float* __restrict__ frag, const float* __restrict__ s_obs, int lane) {
-    const int jrow = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int s4 = 0; s4 < 2; s4++) {
-#pragma unroll
-        for (int to = 0; to < 2; to++) {
-            const float4 a = *reinterpret_cast<const float4*>(frag + ((s4 * 2 + to) * 64 + lane) * 4);
-            const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int s = 4 * s4 + c;
-                if (s < 5) {
-                    const int k = 2 * s + half;
-                    out[to] = MFMA(av[c], k < OBS ? s_obs[jrow * OBS + k] : 0.0f, out[to]);
-                }
-            }
-        }
-    }
-}
-
-// accumulator-layout registers -> transposition tile [index][row]
-template <int T, typename F>
-__device__ __forceinline__ void put_tile(float* __restrict__ tile, const f32x16 (&v)[T], int lane, F f) {
-    const int jrow = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int t = 0; t < T; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) tile[(32 * t + 8 * (r >> 2) + 4 * half + (r & 3)) * TS + jrow] = f(t, r, v[t][r]);
-}
-
-// acc[to][ti] += Td[out][row] (x) Ta[in][row] over the tile's 32 rows; dbias[to] += sum_rows Td[out][row] (lane's parity)
-template <int TO, int TI>
-__device__ __forceinline__ void wgrad(f32x16 (&acc)[TO][TI], float (&dbias)[TO], const float* __restrict__ Td,
-                                      const float* __restrict__ Ta, int lane) {
-    const int i = lane & 31, half = lane >> 5;
-#pragma unroll 4
-    for (int s = 0; s < 16; s++) {
-        const int row = 2 * s + half;
-        float a[TO], b[TI];
-#pragma unroll
-        for (int to = 0; to < TO; to++) {
-            a[to] = Td[(32 * to + i) * TS + row];
-            dbias[to] += a[to];
-        }
-#pragma unroll
-        for (int ti = 0; ti < TI; ti++) b[ti] = Ta[(32 * ti + i) * TS + row];
-#pragma unroll
-        for (int to = 0; to < TO; to++)
-#pragma unroll
-            for (int ti = 0; ti < TI; ti++) acc[to][ti] = MFMA(a[to], b[ti], acc[to][ti]);
-    }
-}
-
-// flush an accumulator tile pair into a row-major [n_out][ld] gradient with atomics
-template <int TO, int TI>
-__device__ __forceinline__ void flush(float* __restrict__ g, int ld, int n_out, int n_in, const f32x16 (&acc)[TO][TI], int lane) {
-    const int j = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int to = 0; to < TO; to++)
-#pragma unroll
-        for (int ti = 0; ti < TI; ti++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int out = 32 * to + 8 * (r >> 2) + 4 * half + (r & 3), in = 32 * ti + j;
-                if (out < n_out && in < n_in) atomicAdd(g + (size_t)out * ld + in, acc[to][ti][r]);
-            }
-}
-
 struct PpoArgs {
     const float *w1, *b1, *w2, *b2, *w3, *b3;
     const float* obs;        // [R,9]

@@ -85,6 +85,7 @@ class DGAILAgent:
         # fused HIP minibatch update of policy / value (ec_ppo_*_grad_ex): every p.grad is a view into one flat buffer
         # per network that the kernels accumulate into, the BC term's autograd adds to, and the DP all-reduce reduces
         self._fg_policy = self._fg_value = None
+        self._noted_torch_disc = False
         if self._fused_ok() and not getattr(args, "ec_torch_update", False):
             self._fg_policy = ppo_device.FlatGrads(self.policy)
             self._fg_value = ppo_device.FlatGrads(self.value)
@@ -161,10 +162,19 @@ class DGAILAgent:
         ln = self.discriminator.compute_loss(sa, th.zeros_like(ones), *self.rng.diffusion_draws(sa.size(0), sa.size(1)))
         return th.exp(-lp) / (th.exp(-lp) + th.exp(-ln) + 1e-8)
 
-    def _update_discriminator(self, agent_sa):
-        """Diffusion discriminator step, dgail_agent.py:203-243."""
+    def _update_discriminator(self, agent_sa, obs=None, actions=None):
+        """Diffusion discriminator step, dgail_agent.py:203-243.  With the rollout's obs / actions given and the fused
+        kernel applicable, the four compute_loss calls and their backward run on ec_diffusion_grad."""
         if len(self.expert_transitions) < self.args.batch_size_run:
             return 0.0, 0.0, 0.0
+        if (obs is not None and self._fused_ok() and self.state_action_dim not in (32, 64)
+                and not getattr(self.args, "ec_torch_update", False)):
+            return self._update_discriminator_fused(obs, actions)
+        if self.device.type == "cuda" and not self._noted_torch_disc:
+            self._noted_torch_disc = True
+            print("DGAILAgent: the diffusion-discriminator update runs on torch autograd, not on ec_diffusion_grad "
+                  "(hidden_dim=%s, obs+actions=%d, ec_torch_update=%s)"
+                  % (self.args.hidden_dim, self.state_action_dim, getattr(self.args, "ec_torch_update", False)))
         prob_expert = self._d_phi(self._expert_sa(agent_sa.size(0)))
         loss_expert = F.binary_cross_entropy(prob_expert, th.ones_like(prob_expert))
         prob_agent = self._d_phi(agent_sa)
@@ -173,6 +183,43 @@ class DGAILAgent:
         self.discriminator_optimizer.zero_grad()
         loss.backward()
         all_reduce_grads_(list(self.discriminator.parameters()), average=True)
+        self.discriminator_optimizer.step()
+        self._disc_update_count += 1
+        return (float(global_mean(loss.detach().reshape(1))), float(global_mean(prob_expert.detach())),
+                float(global_mean(prob_agent.detach())))
+
+    def _update_discriminator_fused(self, obs, actions):
+        """The same step on the fused kernel: per compute_loss call one forward launch (per-row loss) and, once the BCE of
+        D_phi has turned the four loss vectors into per-row coefficients, one forward + backward launch.  Random draws
+        and spectral-norm power iterations happen in the reference's order: expert rows, then per data set the
+        expert-condition call before the agent-condition call (dgail_agent.py:205-221, dgail_network.py:90-91)."""
+        d = self.discriminator
+        obs_f = obs.reshape(-1, self.obs_shape)
+        act_f = actions.reshape(-1)
+        rows = obs_f.shape[0]
+        exp_obs, exp_act = self.expert_transitions.sample_rows(rows)
+        calls, losses = [], []
+        for o, a_ in ((exp_obs, exp_act), (obs_f, act_f)):
+            for c in (1, 0):
+                t, noise = self.rng.diffusion_draws(rows, self.state_action_dim)
+                call = mlp_device.DiffusionLossCall(d, c, o, a_, self.n_actions, t, noise)
+                calls.append(call)
+                losses.append(call.loss(d.R1_LAMBDA).requires_grad_(True))
+
+        def d_phi(lp, ln):
+            return th.exp(-lp) / (th.exp(-lp) + th.exp(-ln) + 1e-8)
+        prob_expert, prob_agent = d_phi(losses[0], losses[1]), d_phi(losses[2], losses[3])
+        loss = (F.binary_cross_entropy(prob_expert, th.ones_like(prob_expert))
+                + F.binary_cross_entropy(prob_agent, th.zeros_like(prob_agent)))
+        coefs = th.autograd.grad(loss, losses)
+        self.discriminator_optimizer.zero_grad()
+        roots, grads = [], []
+        for call, cf in zip(calls, coefs):
+            r, g = call.backward(cf, d.R1_LAMBDA)
+            roots += r
+            grads += g
+        th.autograd.backward(roots, grads)
+        all_reduce_grads_(list(d.parameters()), average=True)
         self.discriminator_optimizer.step()
         self._disc_update_count += 1
         return (float(global_mean(loss.detach().reshape(1))), float(global_mean(prob_expert.detach())),
@@ -358,16 +405,14 @@ class DGAILAgent:
         self._fg_value.zero_()
         ws = world_size()
         # (under data parallelism every rank's share enters with weight 1 / world: the summed gradient is the mean)
-        # The minibatch is gathered first (five small coalesced gathers): the kernels then stream their rows instead
-        # of chasing one random 36-byte row per lane (measured 0.65 -> see DESIGN ms per step at 262 k rows); the index
-        # still travels to the actor pass, which takes a row's agent id from it.
-        obs_b, act_b, lp_b, adv_b, ret_b = obs_f[idx], act_f[idx], logp_old[idx], adv_f[idx], ret_f[idx]
-        _, ent = ppo_device.actor_pass(self.policy, obs_b, None, act_b, None, self.n_agents, old_logp=lp_b, adv=adv_b,
+        # The kernels fetch the minibatch rows through `row_index` themselves (a 36-byte row per lane; gathering the five
+        # tables with torch first and streaming them measured 82 ms against 77 ms per update at 4096 envs).
+        _, ent = ppo_device.actor_pass(self.policy, obs_f, None, act_f, None, self.n_agents, old_logp=logp_old, adv=adv_f,
                                        eps_clip=a.clip_param, entropy_coef=a.entropy_coef, inv_denom=1.0 / (n * ws),
                                        grads=self._fg_policy.flat, loss=losses[0:1], want_entropy=True, row_index=idx,
-                                       logits=True, gathered=True)
-        ppo_device.critic_pass(self.value, obs_b, None, 0, target=ret_b, inv_denom=a.value_loss_coef / (n * ws),
-                               grads=self._fg_value.flat, loss=losses[1:2])
+                                       logits=True)
+        ppo_device.critic_pass(self.value, obs_f, None, 0, target=ret_f, inv_denom=a.value_loss_coef / (n * ws),
+                               grads=self._fg_value.flat, loss=losses[1:2], row_index=idx)
         (bc_w * self._compute_bc_loss(bc) / ws).backward()   # adds into the policy's flat gradient
         all_reduce_sum_(self._fg_policy.flat)
         all_reduce_sum_(self._fg_value.flat)
@@ -527,7 +572,7 @@ class DGAILAgent:
         batch = {"obs": obs, "avail_actions": avail_actions, "actions": actions, "rewards": env_rewards, "masks": masks,
                  "next_obs": next_obs}
         agent_sa = self._prepare_batch(obs, actions)
-        disc_loss, prob_expert, prob_agent = self._update_discriminator(agent_sa)
+        disc_loss, prob_expert, prob_agent = self._update_discriminator(agent_sa, obs, actions)
         gail_disc_loss = self._update_gail_discriminator(agent_sa)
         del agent_sa
         imitation_rewards = self._compute_rewards(obs, actions, env_rewards, t_env)

@@ -128,3 +128,76 @@ def diffusion_reward(params, time_embed, cond_embed, obs, actions, n_actions, t_
                                                   _stream(dev)),
                    "ec_diffusion_reward")
     return tuple(outs)
+
+
+class DiffusionLossCall:
+    """One DiffusionDiscriminator.compute_loss call (dgail_network.py:82-108) for condition `c` on the fused kernel
+    (ec_diffusion_grad), with its backward.
+
+    Construction reads the parametrised weights ONCE with autograd on: in training mode that is one spectral-norm power
+    iteration per hidden layer, what the reference's forward does for the call.  The kernel differentiates with respect
+    to its direct inputs (effective W1x / W2, the per-t first-layer bias, W3, its column sums, b2, b3); `backward`
+    returns those tensors with their gradients, and one torch.autograd.backward over them carries the chain rule to
+    the module's parameters (sigma of the spectral norm, the two embeddings) through a graph of a few 64x64 operations.
+    """
+
+    def __init__(self, disc, c, obs, actions, n_actions, t, noise):
+        lin1, lin2, lin3 = [m for m in disc.mlp.modules() if isinstance(m, th.nn.Linear)]
+        self.SA = SA = OBS_DIM + n_actions
+        self.n_actions = n_actions
+        w1, w2 = lin1.weight, lin2.weight  # effective weights, graph to the originals
+        H = w2.shape[0]
+        if w1.shape[1] != SA + 2 * H or lin3.weight.shape[0] != SA:
+            raise ValueError("diffusion discriminator shapes do not match obs(9)+actions(%d)" % n_actions)
+        bias_t = (lin1.bias + disc.time_embed.weight @ w1[:, SA:SA + H].t()
+                  + disc.cond_embed.weight[int(c)] @ w1[:, SA + H:].t())  # [2, H]
+        w3sum = lin3.weight.sum(0)
+        self.inputs = (w1, bias_t, w2, lin2.bias, lin3.weight, lin3.bias, w3sum)
+        self._dev = tuple(_f32(x, "parameter") for x in self.inputs)
+        self.obs = _f32(obs, "obs").reshape(-1, OBS_DIM)
+        self.rows = rows = self.obs.shape[0]
+        self.actions = actions.to(th.int64).contiguous().reshape(-1)
+        self.t = t.to(th.uint8).contiguous().reshape(-1)
+        self.noise = _f32(noise, "noise").reshape(-1, SA)
+        for x in (self.actions, self.t, self.noise):
+            if x.shape[0] != rows:
+                raise ValueError("rows mismatch")
+        self.H = H
+
+    def _launch(self, coef, loss, grads, r1_lambda):
+        w1, bias_t, w2, b2, w3, b3, w3sum = self._dev
+        dev = self.obs.device
+        with th.cuda.device(dev):
+            _abi.check(_abi.lib().ec_diffusion_grad(_p(w1), int(w1.shape[1]), _p(bias_t), _p(w2), _p(b2), _p(w3), _p(b3),
+                                                    _p(w3sum), _p(self.obs), _p(self.actions), _p(self.t), _p(self.noise),
+                                                    _p(coef), self.rows, int(self.n_actions), int(self.H),
+                                                    C.c_float(r1_lambda), _p(loss), _p(grads), _stream(dev)),
+                       "ec_diffusion_grad")
+
+    def loss(self, r1_lambda=1e-4):
+        """per-row loss [rows] (no gradient)"""
+        out = th.empty((self.rows,), dtype=th.float32, device=self.obs.device)
+        self._launch(None, out, None, r1_lambda)
+        return out
+
+    def backward(self, coef, r1_lambda=1e-4):
+        """coef [rows] = d objective / d loss[r].  Returns (tensors, gradients) for torch.autograd.backward."""
+        SA, H = self.SA, self.H
+        coef = _f32(coef, "coef").reshape(-1)
+        if coef.shape[0] != self.rows:
+            raise ValueError("coef rows mismatch")
+        flat = th.zeros(H * SA + 2 * H + H * H + H + SA * H + SA + H, dtype=th.float32, device=self.obs.device)
+        self._launch(coef, None, flat, r1_lambda)
+        o = 0
+
+        def take(n, shape):
+            nonlocal o
+            v = flat[o:o + n].view(shape)
+            o += n
+            return v
+        g_w1x, g_bsum, g_b1 = take(H * SA, (H, SA)), take(H, (H,)), take(H, (H,))
+        g_w2, g_b2, g_w3, g_b3, g_ws = take(H * H, (H, H)), take(H, (H,)), take(SA * H, (SA, H)), take(SA, (SA,)), take(H, (H,))
+        g_w1 = th.zeros_like(self._dev[0])
+        g_w1[:, :SA] = g_w1x
+        g_bias = th.stack([g_bsum - g_b1, g_b1])
+        return list(self.inputs), [g_w1, g_bias, g_w2, g_b2, g_w3, g_b3, g_ws]
