@@ -55,6 +55,10 @@ class GAILAgent:
         if self._fused_ok() and not getattr(args, "ec_torch_update", False):
             self._fg_actor = ppo_device.FlatGrads(self.actor)
             self._fg_critic = ppo_device.FlatGrads(self.critic)
+        elif self.device.type == "cuda":
+            print("GAILAgent: hidden_dim=%s / activate_fun=%s / ec_torch_update=%s: the actor/critic update runs on torch autograd, "
+                  "not on the fused HIP kernels" % (args.hidden_dim, getattr(args, "activate_fun", "relu"),
+                                                    getattr(args, "ec_torch_update", False)))
 
     # ------------------------------------------------------------------ acting
     def _with_ids(self, obs):

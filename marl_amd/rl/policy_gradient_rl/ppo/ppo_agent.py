@@ -54,6 +54,10 @@ class PPOAgent:
         if self._fused_policy_ok() and not getattr(args, "ec_torch_update", False):
             self._fg_actor = ppo_device.FlatGrads(self.actor)
             self._fg_critic = ppo_device.FlatGrads(self.critic)
+        elif self.device.type == "cuda":
+            print("PPOAgent: hidden_dim=%s / activate_fun=%s / ec_torch_update=%s: the actor/critic update runs on torch autograd, "
+                  "not on the fused HIP kernels" % (args.hidden_dim, getattr(args, "activate_fun", "relu"),
+                                                    getattr(args, "ec_torch_update", False)))
 
     def _with_ids(self, obs):
         ids = self._eye.expand(*obs.shape[:-2], -1, -1)
