@@ -341,6 +341,10 @@ int ec_ppo_critic_grad(const float* w1, const float* b1, const float* w2, const 
 /* flags & EC_PPO_GATHERED: the per-row tables are already in pass order (the caller gathered the minibatch: coalesced
  * reads instead of one random row per lane); row_index then only names each row's agent, (row_index[r]) % n_agents. */
 #define EC_PPO_GATHERED 2
+/* flags & EC_PPO_NLL: the objective is the log-probability of `actions` itself, i.e. loss = -sum mask * logp * inv_denom
+ * (F.cross_entropy of the behaviour-cloning term, dgail_agent.py:255-262); old_logp / adv / eps_clip / entropy_coef
+ * are not read. */
+#define EC_PPO_NLL 4
 int ec_ppo_actor_grad_ex(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                          const float* b3, const float* obs, const int32_t* avail, const int64_t* actions,
                          const float* old_logp, const float* adv, const float* mask, int64_t rows, int32_t n_agents,
@@ -351,6 +355,15 @@ int ec_ppo_critic_grad_ex(const float* w1, const float* b1, const float* w2, con
                           const float* b3, const float* obs, const float* target, const float* mask, int64_t rows,
                           int32_t n_agents, int32_t hidden, float inv_denom, float* grads, float* loss, float* values,
                           const int64_t* row_index, void* stream);
+
+/* GAIL discriminator step of DGAIL, one data set per call: replaces GAILDiscriminator.forward (dgail_network.py:37-50) on
+ * (obs | one-hot action), the loss terms of dgail_agent.py:425-431 and their autograd backward.
+ *   expert != 0: loss += -inv_denom * sum log(p + 1e-8);   expert == 0: loss += -inv_denom * sum log(1 - p + 1e-8)
+ * grads (optional, accumulated into): flat [dW1 | db1 | dW2 | db2 | dW3 | db3] in torch parameter order, w1 [64, 9+n_actions];
+ * prob (optional) [rows] <- p = sigmoid(MLP).  9 + n_actions <= 64. */
+int ec_gail_disc_grad(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                      const float* obs, const int64_t* actions, int64_t rows, int32_t n_actions, int32_t hidden,
+                      int32_t expert, float inv_denom, float* grads, float* loss, float* prob, void* stream);
 
 const char* ec_last_error(void);
 const char* ec_version(void);

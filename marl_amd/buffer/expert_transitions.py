@@ -59,6 +59,14 @@ class ExpertTransitions:
         idx = self.rng.choice_without_replacement(size, n)
         return self.obs[idx], self.actions[idx]
 
+    def sample_transitions_many(self, n, count):
+        """`count` consecutive sample_transitions(n) draws in one go: obs [count,n,N,O], actions [count,n,N] (one size
+        query, one batched draw, one gather)."""
+        size = len(self)
+        n = min(int(n), size)
+        idx = self.rng.choice_without_replacement_many(size, n, int(count))
+        return self.obs[idx], self.actions[idx]
+
     def sample_rows(self, n):
         """n agent-rows with replacement over the concatenation of all stored transitions
         (dgail_agent.py:209-216): returns obs [n,O], actions [n]."""

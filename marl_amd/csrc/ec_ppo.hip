@@ -45,6 +45,12 @@ struct PpoArgs {
     // NULL: the identity.  Outputs (out_a / out_b) are indexed by r.
     const int64_t* row_index;
     int flags;        // EC_PPO_LOGITS: Categorical(logits=...) semantics (exact log-softmax, no [eps, 1-eps] clamp)
+                      // EC_PPO_NLL: the actor objective is the log-prob of `actions` (behaviour cloning)
+    // ec_gail_disc_grad (critic head): the one-hot column of row r is onehot[r] (an action) instead of (row % n_agents),
+    // and the head is the GAIL discriminator's BCE (bce = +1: expert rows, -log(p + 1e-8); -1: agent rows,
+    // -log(1 - p + 1e-8)); out_a receives p = sigmoid(z)
+    const int64_t* onehot;
+    int bce;
 };
 
 // HEAD 0: actor (TO3 output tiles), HEAD 1: critic.  IN1T: tiles of the first layer's dense input (9 + n_agents).
@@ -149,7 +155,11 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             }
         }
         wave_sync();
-        const int agent = (ok && N > 0) ? (int)(irow % N) : 0;  // one-hot agent id (ppo_agent.py:64-65); N = 0: none
+        int agent = (ok && N > 0) ? (int)(irow % N) : 0;  // one-hot agent id (ppo_agent.py:64-65); N = 0: none
+        if (HEAD == 1 && p.onehot) {  // (obs | one-hot action), dgail_agent.py:199-201
+            const int a_ = ok ? (int)p.onehot[trow] : 0;
+            agent = a_ < 0 ? 0 : (a_ >= N ? N - 1 : a_);
+        }
         const float m = ok ? (p.mask ? p.mask[trow] : 1.0f) : 0.0f;
 
         // ------------------------------------------------------------------ forward
@@ -224,18 +234,25 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
                 if (p.out_a) p.out_a[row] = lp_a;
                 if (p.out_b) p.out_b[row] = Hent;
             }
-            if (!p.old_logp) continue;  // forward only
-            const float advr = ok ? p.adv[trow] : 0.0f;
-            const float ratio = expf(lp_a - (ok ? p.old_logp[trow] : 0.0f));
-            const float lo = 1.0f - p.eps_clip, hi = 1.0f + p.eps_clip;
-            const float surr1 = ratio * advr, surr2 = fminf(fmaxf(ratio, lo), hi) * advr;
-            const float inrange = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
-            const float obj = fminf(surr1, surr2) + p.entropy_coef * Hent;
+            const bool nll = (p.flags & EC_PPO_NLL) != 0;
+            if (!p.old_logp && !nll) continue;  // forward only
+            float obj, c1;
+            if (nll) {  // F.cross_entropy(logits, actions) = -mean log-prob (dgail_agent.py:255-262)
+                obj = lp_a;
+                c1 = inr_a;
+            } else {
+                const float advr = ok ? p.adv[trow] : 0.0f;
+                const float ratio = expf(lp_a - (ok ? p.old_logp[trow] : 0.0f));
+                const float lo = 1.0f - p.eps_clip, hi = 1.0f + p.eps_clip;
+                const float surr1 = ratio * advr, surr2 = fminf(fmaxf(ratio, lo), hi) * advr;
+                const float inrange = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
+                obj = fminf(surr1, surr2) + p.entropy_coef * Hent;
+                // torch.min backward: the smaller input takes the gradient, a tie splits it (ratio inside the clip range)
+                const float gr = surr1 < surr2 ? advr : (surr1 > surr2 ? advr * inrange : advr * 0.5f * (1.0f + inrange));
+                c1 = gr * ratio * inr_a;
+            }
             if (half == 0) loss_acc = fmaf(-obj * m, p.inv_denom, loss_acc);
             if (!backward) continue;
-            // torch.min backward: the smaller input takes the gradient, a tie splits it (ratio inside the clip range)
-            const float gr = surr1 < surr2 ? advr : (surr1 > surr2 ? advr * inrange : advr * 0.5f * (1.0f + inrange));
-            const float c1 = gr * ratio * inr_a;
             const float scale = -m * p.inv_denom;
 #pragma unroll
             for (int t = 0; t < T3; t++)
@@ -243,7 +260,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
                 for (int r = 0; r < 16; r++) {
                     const int j = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
                     const float pj = z[t][r];
-                    const float dz = c1 * ((j == act ? 1.0f : 0.0f) - pj) + p.entropy_coef * pj * (gk[t][r] - gbar);
+                    const float dz = c1 * ((j == act ? 1.0f : 0.0f) - pj) + (nll ? 0.0f : p.entropy_coef * pj * (gk[t][r] - gbar));
                     z[t][r] = j < A ? scale * dz : 0.0f;  // d3
                 }
             // dW3 += d3 (x) relu(h2)
@@ -269,12 +286,24 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
                     part = fmaf(w.w, relu(h2[t][4 * q + 3]), part);
                 }
             const float v = part + __shfl_xor(part, 32) + s_b3[0];
-            if (ok && half == 0 && p.out_a) p.out_a[row] = v;
-            if (!p.target) continue;  // forward only
-            const float err = (v - (ok ? p.target[trow] : 0.0f)) * m;
-            if (half == 0) loss_acc = fmaf(err * err, p.inv_denom, loss_acc);
-            if (!backward) continue;
-            const float dv = 2.0f * err * m * p.inv_denom;
+            float dv;
+            if (p.bce) {
+                // GAIL discriminator (dgail_network.py:37-50, dgail_agent.py:425-431): p = sigmoid(v);
+                // loss = -log(p + 1e-8) on expert rows, -log(1 - p + 1e-8) on agent rows
+                const float pr = 1.0f / (1.0f + expf(-v));
+                if (ok && half == 0 && p.out_a) p.out_a[row] = pr;
+                const float arg = p.bce > 0 ? pr + 1e-8f : 1.0f - pr + 1e-8f;
+                if (half == 0) loss_acc = fmaf(-logf(arg) * m, p.inv_denom, loss_acc);
+                if (!backward) continue;
+                dv = (p.bce > 0 ? -1.0f : 1.0f) / arg * (pr * (1.0f - pr)) * m * p.inv_denom;
+            } else {
+                if (ok && half == 0 && p.out_a) p.out_a[row] = v;
+                if (!p.target) continue;  // forward only
+                const float err = (v - (ok ? p.target[trow] : 0.0f)) * m;
+                if (half == 0) loss_acc = fmaf(err * err, p.inv_denom, loss_acc);
+                if (!backward) continue;
+                dv = 2.0f * err * m * p.inv_denom;
+            }
             if (half == 0) gb3c += dv;
 #pragma unroll
             for (int t = 0; t < 2; t++)
@@ -320,8 +349,17 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
     }
 
     // ------------------------------------------------------------------ flush this wave's partial sums
-    if (p.loss && loss_acc != 0.0f) atomicAdd(p.loss, loss_acc);
+    if (p.loss) {  // one atomic per wave: 32 lanes adding to the same word serialise at the memory side
+        float v = loss_acc;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0 && v != 0.0f) atomicAdd(p.loss, v);
+    }
+#ifdef ABL_PPO_NOFLUSH  // diagnostic build (make abl_ppo): what the gradient flush costs
+    if (backward && p.R < 0) {
+#else
     if (backward) {
+#endif
         float* g = p.grads;
         float* gW1p = g;
         float* gb1p = gW1p + (size_t)H * in1;
@@ -388,10 +426,10 @@ int launch_ppo(const PpoArgs& a, hipStream_t stream) {
         EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ppo<HEAD, TO3, IN1T, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (blocks > 256) blocks = 256;  // one block per CU: the row loop amortises weight staging and the final atomics
-        // a minibatch-sized pass (DGAIL: 64 steps of 262 k rows per iteration) is dominated by those fixed costs, every
-        // wave ending with ~150 atomic instructions onto the same 6 k gradient words: at least PPO_MIN_TILES row tiles
-        // per wave before another block is worth its flush
-        static const int min_tiles = getenv("MARL_AMD_PPO_MIN_TILES") ? atoi(getenv("MARL_AMD_PPO_MIN_TILES")) : 16;
+        // MARL_AMD_PPO_MIN_TILES (diagnostic): fewer, longer-running blocks.  Measured at DGAIL's 262 k-row minibatch
+        // passes: 1, 8 and 16 tiles per wave take the same time, more is slower; small passes (the BC term's 640 rows)
+        // want every tile on a wave of its own.
+        static const int min_tiles = getenv("MARL_AMD_PPO_MIN_TILES") ? atoi(getenv("MARL_AMD_PPO_MIN_TILES")) : 1;
         const int64_t want = (tiles + (int64_t)nw * min_tiles - 1) / ((int64_t)nw * min_tiles);
         if (blocks > want) blocks = want < 1 ? 1 : want;
         hipLaunchKernelGGL((k_ppo<HEAD, TO3, IN1T, true>), dim3((unsigned)blocks), dim3(64 * nw), lds, stream, a);
@@ -430,9 +468,9 @@ int ec_ppo_actor_grad_ex(const float* w1, const float* b1, const float* w2, cons
     if (n_agents < 1) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: n_agents %d", n_agents);
     if (n_actions < 1 || n_actions > 64) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: n_actions %d out of range [1,64]", n_actions);
     if (old_logp && !adv) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: old_logp without adv");
-    if (grads && !old_logp) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: grads without old_logp");
+    if (grads && !old_logp && !(flags & EC_PPO_NLL)) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: grads without old_logp");
     PpoArgs a{w1, b1, w2, b2, w3, b3, obs, avail, actions, old_logp, adv, nullptr, mask, rows, n_agents, n_actions,
-              eps_clip, entropy_coef, inv_denom, grads, loss, logp, entropy, row_index, flags};
+              eps_clip, entropy_coef, inv_denom, grads, loss, logp, entropy, row_index, flags, nullptr, 0};
     const int TO3 = n_actions <= 32 ? 1 : 2, IN1T = OBS + n_agents <= 32 ? 1 : 2;
     if (TO3 == 1 && IN1T == 1) return launch_ppo<0, 1, 1>(a, (hipStream_t)stream);
     if (TO3 == 1) return launch_ppo<0, 1, 2>(a, (hipStream_t)stream);
@@ -459,8 +497,22 @@ int ec_ppo_critic_grad_ex(const float* w1, const float* b1, const float* w2, con
     if (int rc = check_common("ec_ppo_critic_grad", need, 7, rows, hidden, n_agents)) return rc;
     if (grads && !target) return ec::fail(EC_EINVAL, "ec_ppo_critic_grad: grads without target");
     PpoArgs a{w1, b1, w2, b2, w3, b3, obs, nullptr, nullptr, nullptr, nullptr, target, mask, rows, n_agents, 1,
-              0.0f, 0.0f, inv_denom, grads, loss, values, nullptr, row_index, 0};
+              0.0f, 0.0f, inv_denom, grads, loss, values, nullptr, row_index, 0, nullptr, 0};
     if (OBS + n_agents <= 32) return launch_ppo<1, 1, 1>(a, (hipStream_t)stream);
+    return launch_ppo<1, 1, 2>(a, (hipStream_t)stream);
+}
+
+int ec_gail_disc_grad(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                      const float* obs, const int64_t* actions, int64_t rows, int32_t n_actions, int32_t hidden,
+                      int32_t expert, float inv_denom, float* grads, float* loss, float* prob, void* stream) {
+    if (rows == 0) return EC_OK;
+    const void* need[] = {w1, b1, w2, b2, w3, b3, obs, actions};
+    if (int rc = check_common("ec_gail_disc_grad", need, 8, rows, hidden, n_actions)) return rc;
+    if (n_actions < 1) return ec::fail(EC_EINVAL, "ec_gail_disc_grad: n_actions %d", n_actions);
+    // the critic instantiation with the action as the one-hot column and the BCE head
+    PpoArgs a{w1, b1, w2, b2, w3, b3, obs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rows, n_actions, 1,
+              0.0f, 0.0f, inv_denom, grads, loss, prob, nullptr, nullptr, 0, actions, expert ? 1 : -1};
+    if (OBS + n_actions <= 32) return launch_ppo<1, 1, 1>(a, (hipStream_t)stream);
     return launch_ppo<1, 1, 2>(a, (hipStream_t)stream);
 }
 

@@ -84,11 +84,13 @@ class DGAILAgent:
         self._eye = th.eye(self.n_agents, device=self.device)
         # fused HIP minibatch update of policy / value (ec_ppo_*_grad_ex): every p.grad is a view into one flat buffer
         # per network that the kernels accumulate into, the BC term's autograd adds to, and the DP all-reduce reduces
-        self._fg_policy = self._fg_value = None
+        self._fg_policy = self._fg_value = self._fg_gail = self._fg_bc = None
         self._noted_torch_disc = False
         if self._fused_ok() and not getattr(args, "ec_torch_update", False):
             self._fg_policy = ppo_device.FlatGrads(self.policy)
             self._fg_value = ppo_device.FlatGrads(self.value)
+            self._fg_gail = ppo_device.FlatGrads(self.gail_discriminator)
+            self._fg_bc = th.zeros_like(self._fg_policy.flat)  # the BC term's gradient before its weight
         elif self.device.type == "cuda":
             print("DGAILAgent: hidden_dim=%s / obs_shape=%s / ec_torch_update: the policy/value update runs on torch "
                   "autograd, not on the fused HIP kernels" % (args.hidden_dim, self.obs_shape))
@@ -175,6 +177,8 @@ class DGAILAgent:
             print("DGAILAgent: the diffusion-discriminator update runs on torch autograd, not on ec_diffusion_grad "
                   "(hidden_dim=%s, obs+actions=%d, ec_torch_update=%s)"
                   % (self.args.hidden_dim, self.state_action_dim, getattr(self.args, "ec_torch_update", False)))
+        if agent_sa is None:
+            agent_sa = self._prepare_batch(obs, actions)
         prob_expert = self._d_phi(self._expert_sa(agent_sa.size(0)))
         loss_expert = F.binary_cross_entropy(prob_expert, th.ones_like(prob_expert))
         prob_agent = self._d_phi(agent_sa)
@@ -225,10 +229,26 @@ class DGAILAgent:
         return (float(global_mean(loss.detach().reshape(1))), float(global_mean(prob_expert.detach())),
                 float(global_mean(prob_agent.detach())))
 
-    def _update_gail_discriminator(self, agent_sa):
-        """dgail_agent.py:418-444"""
+    def _update_gail_discriminator(self, agent_sa, obs=None, actions=None):
+        """dgail_agent.py:418-444.  With the rollout's obs / actions given and the fused kernels available: one
+        ec_gail_disc_grad launch per data set (forward, -log terms, backward) into the discriminator's flat gradient."""
         if len(self.expert_transitions) < self.args.batch_size_run:
             return 0.0
+        if obs is not None and self._fg_gail is not None:
+            obs_f, act_f = obs.reshape(-1, self.obs_shape), actions.reshape(-1)
+            n, ws = obs_f.shape[0], world_size()
+            exp_obs, exp_act = self.expert_transitions.sample_rows(n)
+            self._fg_gail.bind()
+            self._fg_gail.zero_()
+            loss = th.zeros(1, device=self.device)
+            for o, a_, expert in ((exp_obs, exp_act, True), (obs_f, act_f, False)):
+                ppo_device.gail_disc_pass(self.gail_discriminator, o, a_, expert, inv_denom=1.0 / (n * ws),
+                                          grads=self._fg_gail.flat, loss=loss)
+            all_reduce_sum_(self._fg_gail.flat)
+            self.gail_discriminator_optimizer.step()
+            return float(global_mean(loss * ws))
+        if agent_sa is None:
+            agent_sa = self._prepare_batch(obs, actions)
         prob_expert = self.gail_discriminator(self._expert_sa(agent_sa.size(0)))
         prob_agent = self.gail_discriminator(agent_sa)
         loss = -(th.log(prob_expert + 1e-8).mean() + th.log(1 - prob_agent + 1e-8).mean())
@@ -340,9 +360,11 @@ class DGAILAgent:
         totals = graph["totals"] if graph is not None else th.zeros(3, device=self.device)
         for _ in range(a.ppo_epochs):
             perm = self.rng.permutation(rows)
+            # the epoch's BC samples in one batched draw (same draws, same order as one per minibatch step)
+            bc_obs, bc_act = self.expert_transitions.sample_transitions_many(a.batch_expert_transitions, n_mb)
             for i in range(n_mb):
                 idx = perm[i * mb:(i + 1) * mb]
-                bc = self.expert_transitions.sample_transitions(a.batch_expert_transitions)
+                bc = (bc_obs[i], bc_act[i])
                 if graph is not None and idx.shape[0] == mb and bc[1].shape == graph["bc_act"].shape:
                     graph["idx"].copy_(idx)
                     graph["bc_obs"].copy_(bc[0])
@@ -381,9 +403,11 @@ class DGAILAgent:
         totals = graph["totals"] if graph is not None else th.zeros(3, device=self.device)
         for _ in range(a.ppo_epochs):
             perm = self.rng.permutation(rows)
+            # the epoch's BC samples in one batched draw (same draws, same order as one per minibatch step)
+            bc_obs, bc_act = self.expert_transitions.sample_transitions_many(a.batch_expert_transitions, n_mb)
             for i in range(n_mb):
                 idx = perm[i * mb:(i + 1) * mb]
-                bc = self.expert_transitions.sample_transitions(a.batch_expert_transitions)
+                bc = (bc_obs[i], bc_act[i])
                 if graph is not None and idx.shape[0] == mb and bc[1].shape == graph["bc_act"].shape:
                     graph["idx"].copy_(idx)
                     graph["bc_obs"].copy_(bc[0])
@@ -413,7 +437,12 @@ class DGAILAgent:
                                        logits=True)
         ppo_device.critic_pass(self.value, obs_f, None, 0, target=ret_f, inv_denom=a.value_loss_coef / (n * ws),
                                grads=self._fg_value.flat, loss=losses[1:2], row_index=idx)
-        (bc_w * self._compute_bc_loss(bc) / ws).backward()   # adds into the policy's flat gradient
+        # BC term (dgail_agent.py:255-262, 309): the same kernel with the cross-entropy objective on the expert rows,
+        # into a buffer of its own so that its weight stays a device scalar (the captured step outlives one value of it)
+        self._fg_bc.zero_()
+        ppo_device.actor_pass(self.policy, bc[0], None, bc[1], None, self.n_agents, inv_denom=1.0 / (bc[1].numel() * ws),
+                              grads=self._fg_bc, logits=True, nll=True)
+        self._fg_policy.flat.addcmul_(self._fg_bc, bc_w)
         all_reduce_sum_(self._fg_policy.flat)
         all_reduce_sum_(self._fg_value.flat)
         th.nn.utils.clip_grad_norm_(self.policy.parameters(), a.grad_norm_clip)
@@ -571,9 +600,10 @@ class DGAILAgent:
         obs, avail_actions, actions, env_rewards, masks, next_obs = self.buffer.sample()
         batch = {"obs": obs, "avail_actions": avail_actions, "actions": actions, "rewards": env_rewards, "masks": masks,
                  "next_obs": next_obs}
-        agent_sa = self._prepare_batch(obs, actions)
+        # the (obs | one-hot action) matrix is only materialised for the torch formulation of the two steps
+        agent_sa = None if self._fg_gail is not None else self._prepare_batch(obs, actions)
         disc_loss, prob_expert, prob_agent = self._update_discriminator(agent_sa, obs, actions)
-        gail_disc_loss = self._update_gail_discriminator(agent_sa)
+        gail_disc_loss = self._update_gail_discriminator(agent_sa, obs, actions)
         del agent_sa
         imitation_rewards = self._compute_rewards(obs, actions, env_rewards, t_env)
         batch["rewards"] = imitation_rewards

@@ -39,6 +39,7 @@ def _rows(obs):
 
 EC_PPO_LOGITS = 1
 EC_PPO_GATHERED = 2
+EC_PPO_NLL = 4
 
 
 def _index(row_index, dev):
@@ -51,12 +52,14 @@ def _index(row_index, dev):
 
 def actor_pass(actor, obs, avail, actions, mask, n_agents, old_logp=None, adv=None, eps_clip=0.2, entropy_coef=0.0,
                inv_denom=1.0, grads=None, loss=None, want_logp=False, want_entropy=False, row_index=None, logits=False,
-               gathered=False):
+               gathered=False, nll=False):
     """One launch.  Forward only when old_logp is None (returns logp / entropy); with old_logp and adv it accumulates
     the loss into `loss` [1] and, if `grads` (flat, parameter order) is given, the gradient into it.
     row_index [r] (optional): the pass takes rows row_index[0..r) of the per-row tables (a shuffled minibatch), outputs
     are in pass order; avail / mask may be None (no action mask / all ones); logits=True: Categorical(logits=...).
-    gathered=True: the tables ARE the minibatch (gathered by the caller); row_index only names each row's agent."""
+    gathered=True: the tables ARE the minibatch (gathered by the caller); row_index only names each row's agent.
+    nll=True: the objective is the log-prob of `actions` (loss = -inv_denom * sum mask * logp: a cross-entropy term);
+    old_logp / adv are not needed."""
     w1, b1, w2, b2, w3, b3 = linear_params(actor)
     obs, table_rows = _rows(obs)
     dev = obs.device
@@ -84,7 +87,8 @@ def actor_pass(actor, obs, avail, actions, mask, n_agents, old_logp=None, adv=No
                                                    int(A), int(w2.shape[0]), C.c_float(eps_clip),
                                                    C.c_float(entropy_coef), C.c_float(inv_denom), _p(grads), _p(loss),
                                                    _p(logp), _p(ent), _p(row_index),
-                                                   (EC_PPO_LOGITS if logits else 0) | (EC_PPO_GATHERED if gathered else 0),
+                                                   (EC_PPO_LOGITS if logits else 0) | (EC_PPO_GATHERED if gathered else 0)
+                                                   | (EC_PPO_NLL if nll else 0),
                                                    _stream(dev)), "ec_ppo_actor_grad_ex")
     return logp, ent
 
@@ -110,3 +114,23 @@ def critic_pass(critic, obs, mask, n_agents, target=None, inv_denom=1.0, grads=N
                                                     C.c_float(inv_denom), _p(grads), _p(loss), _p(values),
                                                     _p(row_index), _stream(dev)), "ec_ppo_critic_grad_ex")
     return values
+
+
+def gail_disc_pass(disc, obs, actions, expert, inv_denom=1.0, grads=None, loss=None, want_prob=False):
+    """One data set of DGAIL's GAIL-discriminator step (ec_gail_disc_grad): p = sigmoid(MLP(obs | one-hot action)),
+    loss += -inv_denom * sum log(p + 1e-8) (expert) or -inv_denom * sum log(1 - p + 1e-8) (agent), gradient into `grads`
+    (flat, parameter order).  Returns p [rows] when want_prob."""
+    w1, b1, w2, b2, w3, b3 = linear_params(disc)
+    obs, rows = _rows(obs)
+    dev = obs.device
+    n_actions = w1.shape[1] - OBS_DIM
+    actions = actions.to(th.int64).contiguous().reshape(-1)
+    if actions.shape[0] != rows:
+        raise ValueError("rows mismatch")
+    prob = th.empty(rows, dtype=th.float32, device=dev) if want_prob else None
+    with th.cuda.device(dev):
+        _abi.check(_abi.lib().ec_gail_disc_grad(_p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(obs), _p(actions), rows,
+                                                int(n_actions), int(w2.shape[0]), 1 if expert else 0,
+                                                C.c_float(inv_denom), _p(grads), _p(loss), _p(prob), _stream(dev)),
+                   "ec_gail_disc_grad")
+    return prob

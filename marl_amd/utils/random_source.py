@@ -22,6 +22,13 @@ class RandomSource:
             return th.rand(size, device=self.device, generator=self.generator).topk(n).indices
         return th.randperm(size, device=self.device, generator=self.generator)[:n]
 
+    def choice_without_replacement_many(self, size, n, count):
+        """`count` consecutive choice_without_replacement(size, n) draws as one [count, n] tensor (one batched top-k:
+        the minibatch steps of an epoch take their expert samples from it without a launch sequence per step)"""
+        if n * 4 <= size:
+            return th.rand(count, size, device=self.device, generator=self.generator).topk(n, dim=1).indices
+        return th.stack([self.choice_without_replacement(size, n) for _ in range(count)])
+
     def choice_with_replacement(self, size, n):
         """np.random.choice(size, n, replace=True)"""
         return th.randint(0, size, (int(n),), device=self.device, generator=self.generator)
@@ -57,6 +64,9 @@ class ReplaySource(RandomSource):
 
     def choice_without_replacement(self, size, n):
         return self._next("choice", n).long()
+
+    def choice_without_replacement_many(self, size, n, count):
+        return th.stack([self._next("choice", n).long() for _ in range(count)])
 
     def choice_with_replacement(self, size, n):
         return self._next("choice", n).long()

@@ -123,3 +123,81 @@ def test_critic_loss_and_gradients(N, rows):
         assert err <= 1e-4 * scale + 1e-9, (name, err, scale)
     v2 = ppo_device.critic_pass(critic, obs.to(dev), mask.to(dev), N, want_values=True)   # forward only
     assert th.equal(v2, vals)
+
+
+@pytest.mark.parametrize("N,rows", [(10, 640), (10, 33), (40, 5000)])
+def test_actor_nll_objective(N, rows):
+    """EC_PPO_NLL: the behaviour-cloning term of DGAIL's minibatch step (dgail_agent.py:255-262) — F.cross_entropy of the
+    policy's logits on expert actions — loss and gradients against fp64 autograd."""
+    from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import PolicyNet
+    from marl_amd.utils import ppo_device
+    dev = th.device("cuda")
+    A = N + 1
+    th.manual_seed(3 * N + rows)
+    pol = PolicyNet(9 + N, A, 64)
+    with th.no_grad():
+        for p in pol.parameters():
+            p.mul_(2.0)
+    obs, _, actions, _, _, _ = _batch(N, rows, 77)
+    ref = copy.deepcopy(pol).double()
+    ids = th.eye(N, dtype=th.float64)[th.arange(rows) % N]
+    w = 0.37
+    loss = w * F.cross_entropy(ref(th.cat([obs.double(), ids], -1)), actions)
+    loss.backward()
+    want = th.cat([p.grad.reshape(-1) for p in ref.parameters()])
+
+    pol = pol.to(dev)
+    fg = ppo_device.FlatGrads(pol)
+    out = th.zeros(1, device=dev)
+    ppo_device.actor_pass(pol, obs.to(dev), None, actions.to(dev), None, N, inv_denom=w / rows, grads=fg.flat, loss=out,
+                          logits=True, nll=True)
+    th.cuda.synchronize()
+    assert abs(float(out) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
+    off = 0
+    for name, p in ref.named_parameters():
+        k = p.numel()
+        g, wv = fg.flat[off:off + k].double().cpu(), want[off:off + k]
+        assert float((g - wv).abs().max()) <= 1e-4 * float(wv.abs().max()) + 1e-9, name
+        off += k
+
+
+@pytest.mark.parametrize("N,rows", [(10, 1), (10, 100000), (40, 7777), (23, 500)])
+def test_gail_disc_loss_and_gradients(N, rows):
+    """ec_gail_disc_grad: DGAIL's GAIL-discriminator step (dgail_network.py:37-50, dgail_agent.py:425-431) — both data
+    sets accumulated into one flat gradient — against fp64 autograd; p = sigmoid(MLP) per row."""
+    from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import GAILDiscriminator
+    from marl_amd.utils import ppo_device
+    dev = th.device("cuda")
+    A = N + 1
+    th.manual_seed(5 * N + rows)
+    disc = GAILDiscriminator(9 + A, 64)
+    with th.no_grad():
+        for p in disc.parameters():
+            p.mul_(2.0)
+    obs_e, _, act_e, _, _, _ = _batch(N, rows, 11)
+    obs_a, _, act_a, _, _, _ = _batch(N, rows, 12)
+    ref = copy.deepcopy(disc).double()
+    eye = th.eye(A, dtype=th.float64)
+    pe = ref(th.cat([obs_e.double(), eye[act_e]], -1))
+    pa = ref(th.cat([obs_a.double(), eye[act_a]], -1))
+    loss = -(th.log(pe + 1e-8).mean() + th.log(1 - pa + 1e-8).mean())
+    loss.backward()
+    want = th.cat([p.grad.reshape(-1) for p in ref.parameters()])
+
+    disc = disc.to(dev)
+    fg = ppo_device.FlatGrads(disc)
+    out = th.zeros(1, device=dev)
+    got_pe = ppo_device.gail_disc_pass(disc, obs_e.to(dev), act_e.to(dev), True, inv_denom=1.0 / rows, grads=fg.flat,
+                                       loss=out, want_prob=True)
+    got_pa = ppo_device.gail_disc_pass(disc, obs_a.to(dev), act_a.to(dev), False, inv_denom=1.0 / rows, grads=fg.flat,
+                                       loss=out, want_prob=True)
+    th.cuda.synchronize()
+    assert np.allclose(got_pe.cpu().numpy(), pe.detach().squeeze(-1).numpy(), rtol=1e-5, atol=1e-6)
+    assert np.allclose(got_pa.cpu().numpy(), pa.detach().squeeze(-1).numpy(), rtol=1e-5, atol=1e-6)
+    assert abs(float(out) - float(loss)) <= 2e-5 * max(1.0, abs(float(loss)))
+    off = 0
+    for name, p in ref.named_parameters():
+        k = p.numel()
+        g, wv = fg.flat[off:off + k].double().cpu(), want[off:off + k]
+        assert float((g - wv).abs().max()) <= 1e-4 * float(wv.abs().max()) + 1e-9, name
+        off += k
