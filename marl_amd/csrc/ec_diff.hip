@@ -73,10 +73,10 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int jrow = lane & 31, half = lane >> 5;
-    float* s_x = s_wave + (size_t)wave * (2 * 32 * SAp + (BWD ? 2 * 64 * TS : 0));
+    float* s_x = s_wave + (size_t)wave * (2 * 32 * SAp + (BWD ? 2 * TILE : 0));
     float* s_noise = s_x + 32 * SAp;
     float* Td = s_noise + 32 * SAp;
-    float* Ta = Td + 64 * TS;
+    float* Ta = Td + TILE;
 
     // persistent gradient accumulators of this wave
     f32x16 gW1[2][TX], gW2[2][2], gW3[TX][2], gw3s[2];
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
         wave_sync();
         put_tile<2>(Td, d1, lane, ident);
         for (int in = half; in < 32 * TX; in += 2)
-            Ta[in * TS + jrow] = in < SA ? s_x[jrow * SAp + in] : (in == SA ? (float)tr : 0.0f);
+            Ta[in * TSTR + jrow] = in < SA ? s_x[jrow * SAp + in] : (in == SA ? (float)tr : 0.0f);
         wave_sync();
         wgrad<2, TX>(gW1, gb1, Td, Ta, lane);
     }
@@ -300,7 +300,7 @@ constexpr size_t DIFF_LDS_MAX = 160 * 1024;
 size_t diff_lds_bytes(int TX, int SA, int nw, bool bwd) {
     size_t f = (size_t)16 * TX * 2 * 64 + 2 * (32 * 2 * 64) + 2 * ((size_t)32 * TX * 64) + (bwd ? (size_t)16 * TX * 2 * 64 : 0);
     f += 2 * H + H + 32 * TX + H;
-    const size_t per_wave = (size_t)2 * 32 * (SA | 1) + (bwd ? 2 * 64 * TS : 0);
+    const size_t per_wave = (size_t)2 * 32 * (SA | 1) + (bwd ? 2 * TILE : 0);
     return sizeof(float) * (f + nw * per_wave);
 }
 

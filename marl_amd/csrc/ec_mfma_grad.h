@@ -1,12 +1,17 @@
 // ec_mfma_grad.h — device helpers shared by the fused forward + backward kernels (ec_ppo.hip, ec_diff.hip): the
-// register-chained 32x32x2 layer on one group of 32 rows, the accumulator -> [index][row] transposition tiles, the
+// register-chained 32x32x2 layer on one group of 32 rows, the per-wave [index][row] exchange tiles, the
 // weight-gradient accumulation with the row index as the MFMA's K dimension, and the atomic flush.
 #pragma once
 #include "ec_mfma.h"
 
 namespace {
 
-constexpr int TS = 33;                   // row stride of the transposition tiles
+// Exchange tiles between the accumulator layout (a lane holds 16 outputs of ONE row) and the weight-gradient MFMA's
+// operands (a lane holds ONE output of 16 rows): [index][row], row stride TSTR = 33 floats (conflict-free both ways).
+// (A [row][index] layout with one 16-byte store per four registers was measured too: same time, and the 4-register
+// alignment it asks for costs the wide instantiations (N = 40) 1.5 KB of spills per lane.)
+constexpr int TSTR = 33;
+constexpr int TILE = 64 * TSTR;          // floats per tile
 
 // out[to] += frag * f(in): TI input tiles of 16 accumulator registers (k order kperm), one group of 32 rows
 template <int TO, int TI, typename F>
@@ -47,20 +52,26 @@ __device__ __forceinline__ void chain_obs(f32x16 (&out)[2], const float* __restr
     }
 }
 
-// accumulator-layout registers -> transposition tile [index][row]
+// accumulator-layout registers -> exchange tile [index][row]
 template <int T, typename F>
 __device__ __forceinline__ void put_tile(float* __restrict__ tile, const f32x16 (&v)[T], int lane, F f) {
+#ifdef ABL_NO_PUT  // diagnostic builds (make abl_ppo): what the transposition stores / the weight-gradient MFMAs cost
+    return;
+#endif
     const int jrow = lane & 31, half = lane >> 5;
 #pragma unroll
     for (int t = 0; t < T; t++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) tile[(32 * t + 8 * (r >> 2) + 4 * half + (r & 3)) * TS + jrow] = f(t, r, v[t][r]);
+        for (int r = 0; r < 16; r++) tile[(32 * t + 8 * (r >> 2) + 4 * half + (r & 3)) * TSTR + jrow] = f(t, r, v[t][r]);
 }
 
 // acc[to][ti] += Td[out][row] (x) Ta[in][row] over the tile's 32 rows; dbias[to] += sum_rows Td[out][row] (lane's parity)
 template <int TO, int TI>
 __device__ __forceinline__ void wgrad(f32x16 (&acc)[TO][TI], float (&dbias)[TO], const float* __restrict__ Td,
                                       const float* __restrict__ Ta, int lane) {
+#ifdef ABL_NO_WGRAD
+    return;
+#endif
     const int i = lane & 31, half = lane >> 5;
 #pragma unroll 4
     for (int s = 0; s < 16; s++) {
@@ -68,11 +79,11 @@ __device__ __forceinline__ void wgrad(f32x16 (&acc)[TO][TI], float (&dbias)[TO],
         float a[TO], b[TI];
 #pragma unroll
         for (int to = 0; to < TO; to++) {
-            a[to] = Td[(32 * to + i) * TS + row];
+            a[to] = Td[(32 * to + i) * TSTR + row];
             dbias[to] += a[to];
         }
 #pragma unroll
-        for (int ti = 0; ti < TI; ti++) b[ti] = Ta[(32 * ti + i) * TS + row];
+        for (int ti = 0; ti < TI; ti++) b[ti] = Ta[(32 * ti + i) * TSTR + row];
 #pragma unroll
         for (int to = 0; to < TO; to++)
 #pragma unroll

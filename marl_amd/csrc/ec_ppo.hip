@@ -25,6 +25,17 @@
 namespace {
 
 constexpr float EPS32 = 1.1920929e-07f;  // torch.finfo(float32).eps: Categorical clamps probs to [eps, 1-eps]
+#ifdef ABL_PPO_STAMPS  // diagnostic build (make abl_ppo): shader-clock time per section of the tile loop, wave 0 of block 0
+#define PST(i)                                              \
+    do {                                                    \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        pst[i] += now_ - pst_prev;                          \
+        pst_prev = now_;                                    \
+    } while (0)
+#else
+#define PST(i)
+#endif
+
 struct PpoArgs {
     const float *w1, *b1, *w2, *b2, *w3, *b3;
     const float* obs;        // [R,9]
@@ -95,10 +106,10 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int jrow = lane & 31, half = lane >> 5;
     const int availw = HEAD == 0 ? 32 * A : 0;
-    float* s_obs = s_wave + (size_t)wave * (32 * OBS + 4 + availw + (BWD ? 2 * 64 * TS : 0));
+    float* s_obs = s_wave + (size_t)wave * (32 * OBS + 4 + availw + (BWD ? 2 * TILE : 0));
     int32_t* s_av = reinterpret_cast<int32_t*>(s_obs + 32 * OBS + 4);
     float* Td = s_obs + 32 * OBS + 4 + availw;
-    float* Ta = Td + 64 * TS;
+    float* Ta = Td + TILE;
     constexpr bool backward = BWD;  // the launcher picks the instantiation by p.grads
 
     // persistent gradient accumulators of this wave
@@ -125,42 +136,105 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             for (int r = 0; r < 16; r++) gW3[a][b][r] = 0.0f;
     }
 
+#ifdef ABL_PPO_STAMPS
+    unsigned long long pst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pst_prev = __builtin_readcyclecounter();
+#endif
+    // BWD passes fetch their per-row inputs ONE TILE AHEAD into registers (and the minibatch index two tiles ahead): a wave
+    // is alone on its SIMD there, so a load issued where its value is needed stalls the whole pipe for a memory round
+    // trip -- measured 20 % of a pass (observation tile, then target / advantage / old log-prob / mask / action each
+    // behind its own wait).  The forward-only passes run two waves per SIMD and keep their registers: they fetch in place.
+    constexpr bool PF = BWD && (HEAD == 1 || (TO3 == 1 && IN1T == 1));  // (the wider actor instantiations have no registers to spare)
+    constexpr int AVP = (HEAD == 0 && PF) ? 6 : 0;  // prefetched mask words per lane (32 x A <= 384); the rest in place
+    struct Pre {
+        float obs[5];  // 32 x 9 floats over 64 lanes
+        int32_t av[AVP > 0 ? AVP : 1];
+        int64_t irow, trow, rowbase;
+        int act, onehot, nvalid;
+        float olp, adv, m, tgt;
+        bool ok;
+    };
     const int64_t n_tiles = (p.R + 31) / 32;
-    for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += (int64_t)gridDim.x * nw) {
-        const int64_t rowbase = tile * 32;
-        const int64_t row = rowbase + jrow;
-        const bool ok = row < p.R;
-        const bool gathered = (p.flags & EC_PPO_GATHERED) != 0;  // tables already in pass order: the index only names the agent
-        const int64_t irow = ok ? (p.row_index ? p.row_index[row] : row) : 0;
-        const int64_t trow = gathered ? (ok ? row : 0) : irow;  // row of the per-row tables
+    const bool gathered = (p.flags & EC_PPO_GATHERED) != 0;  // tables already in pass order: the index only names the agent
+    const bool indexed = p.row_index && !gathered;
+    const auto load_index = [&](int64_t tile) -> int64_t {
+        const int64_t row = tile * 32 + jrow;
+        return (p.row_index && tile < n_tiles && row < p.R) ? p.row_index[row] : 0;
+    };
+    const auto fetch = [&](int64_t tile, int64_t index_of_row) -> Pre {
+        Pre f;
+        const int64_t rowbase = tile * 32, row = rowbase + jrow;
+        const bool live = tile < n_tiles;
+        f.rowbase = rowbase;
+        f.ok = live && row < p.R;
+        f.irow = f.ok ? (p.row_index ? index_of_row : row) : 0;
+        f.trow = gathered ? (f.ok ? row : 0) : f.irow;  // row of the per-row tables
+        f.nvalid = !live ? 0 : (int)(p.R - rowbase < 32 ? p.R - rowbase : 32);
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int i = lane + 64 * u, r = i / OBS;  // (rows r <= 31: their lanes hold a valid trow)
+            const int64_t src = indexed ? (int64_t)__shfl((long long)f.trow, r & 31) : rowbase + r;
+            f.obs[u] = (i < 32 * OBS && r < f.nvalid) ? p.obs[src * OBS + (i - r * OBS)] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < AVP; u++) {
+            f.av[u] = 0;
+            if (HEAD == 0 && p.avail) {
+                const int i = lane + 64 * u, r = i < 32 * A ? i / A : 0;
+                const int64_t src = indexed ? (int64_t)__shfl((long long)f.trow, r) : rowbase + r;
+                if (i < 32 * A && r < f.nvalid) f.av[u] = p.avail[src * A + (i - r * A)];
+            }
+        }
+        f.act = (HEAD == 0 && f.ok) ? (int)p.actions[f.trow] : 0;
+        f.onehot = (HEAD == 1 && p.onehot && f.ok) ? (int)p.onehot[f.trow] : 0;
+        f.olp = (HEAD == 0 && p.old_logp && f.ok) ? p.old_logp[f.trow] : 0.0f;
+        f.adv = (HEAD == 0 && p.old_logp && f.ok) ? p.adv[f.trow] : 0.0f;
+        f.tgt = (HEAD == 1 && p.target && f.ok) ? p.target[f.trow] : 0.0f;
+        f.m = f.ok ? (p.mask ? p.mask[f.trow] : 1.0f) : 0.0f;
+        return f;
+    };
+    const int64_t tile0 = (int64_t)blockIdx.x * nw + wave, tstride = (int64_t)gridDim.x * nw;
+    int64_t idx_next = 0, idx_next2 = 0;
+    Pre cur, nxt;
+    if (PF) {
+        idx_next = load_index(tile0 + tstride);
+        cur = fetch(tile0, load_index(tile0));
+        nxt = cur;
+    }
+    for (int64_t tile = tile0; tile < n_tiles; tile += tstride) {
+        if (PF) {
+            if (tile != tile0) {
+                cur = nxt;
+                idx_next = idx_next2;
+            }
+            nxt = fetch(tile + tstride, idx_next);  // in flight while this tile computes
+            idx_next2 = load_index(tile + 2 * tstride);
+        } else {
+            cur = fetch(tile, load_index(tile));
+        }
+        const int64_t row = tile * 32 + jrow;
+        const bool ok = cur.ok;
+        const int64_t irow = cur.irow;
         wave_sync();
-        {
-            const int64_t nvalid = (p.R - rowbase < 32 ? p.R - rowbase : 32);
-            if (p.row_index && !gathered) {
-                for (int i = lane; i < 32 * OBS; i += 64) {  // (source lanes r <= 31 are active in every trip, the last included)
-                    const int r = i / OBS;
-                    const int64_t src = __shfl((long long)trow, r);
-                    s_obs[i] = r < nvalid ? p.obs[src * OBS + (i - r * OBS)] : 0.0f;
-                }
-                if (HEAD == 0 && p.avail)
-                    for (int i0 = 0; i0 < 32 * A; i0 += 64) {
-                        const int i = i0 + lane, r = i < 32 * A ? i / A : 0;
-                        const int64_t src = __shfl((long long)trow, r);
-                        if (i < 32 * A) s_av[i] = r < nvalid ? p.avail[src * A + (i - r * A)] : 0;
-                    }
-            } else {
-                for (int i = lane; i < 32 * OBS; i += 64) s_obs[i] = i < nvalid * OBS ? p.obs[rowbase * OBS + i] : 0.0f;
-                if (HEAD == 0 && p.avail)
-                    for (int i = lane; i < 32 * A; i += 64) s_av[i] = i < nvalid * A ? p.avail[rowbase * A + i] : 0;
+#pragma unroll
+        for (int u = 0; u < 5; u++)
+            if (lane + 64 * u < 32 * OBS) s_obs[lane + 64 * u] = cur.obs[u];
+        if (HEAD == 0 && p.avail) {
+#pragma unroll
+            for (int u = 0; u < AVP; u++)
+                if (lane + 64 * u < 32 * A) s_av[lane + 64 * u] = cur.av[u];
+            for (int i0 = 64 * AVP; i0 < 32 * A; i0 += 64) {  // mask words beyond the prefetched ones
+                const int i = i0 + lane, r = i < 32 * A ? i / A : 0;
+                const int64_t src = indexed ? (int64_t)__shfl((long long)cur.trow, r) : cur.rowbase + r;
+                if (i < 32 * A) s_av[i] = r < cur.nvalid ? p.avail[src * A + (i - r * A)] : 0;
             }
         }
         wave_sync();
-        int agent = (ok && N > 0) ? (int)(irow % N) : 0;  // one-hot agent id (ppo_agent.py:64-65); N = 0: none
-        if (HEAD == 1 && p.onehot) {  // (obs | one-hot action), dgail_agent.py:199-201
-            const int a_ = ok ? (int)p.onehot[trow] : 0;
-            agent = a_ < 0 ? 0 : (a_ >= N ? N - 1 : a_);
-        }
-        const float m = ok ? (p.mask ? p.mask[trow] : 1.0f) : 0.0f;
+        PST(0);
+        // one-hot agent id (ppo_agent.py:64-65); N = 0: none.  (32-bit remainder where the row number allows it)
+        int agent = (ok && N > 0) ? (irow < 0x7fffffffll ? (int)((unsigned)irow % (unsigned)N) : (int)(irow % N)) : 0;
+        if (HEAD == 1 && p.onehot)  // (obs | one-hot action), dgail_agent.py:199-201
+            agent = cur.onehot < 0 ? 0 : (cur.onehot >= N ? N - 1 : cur.onehot);
+        const float m = cur.m;
 
         // ------------------------------------------------------------------ forward
         f32x16 h1[2], h2[2];
@@ -169,14 +243,16 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
         acc_init<2>(h2, s_b2, half);
         chain_obs(h1, s_f1, s_obs, lane);
         chain<2, 2>(h2, s_f2, h1, lane, [](int, int, float x) { return relu(x); });
+        PST(1);
 
         f32x16 d2[2];  // d loss / d h2 (pre-activation), accumulator layout
         if (HEAD == 0) {
             f32x16 z[T3];
             acc_init<T3>(z, s_b3, half);
             chain<T3, 2>(z, s_f3, h2, lane, [](int, int, float x) { return relu(x); });
+            PST(2);
             // ---- head: masked softmax, Categorical log-prob / entropy, clipped surrogate (ppo_agent.py:76-83,135-141)
-            const int act = ok ? (int)p.actions[trow] : 0;
+            const int act = cur.act;
             const bool clampp = !(p.flags & EC_PPO_LOGITS);
             float mx = -3.0e38f;
 #pragma unroll
@@ -241,8 +317,8 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
                 obj = lp_a;
                 c1 = inr_a;
             } else {
-                const float advr = ok ? p.adv[trow] : 0.0f;
-                const float ratio = expf(lp_a - (ok ? p.old_logp[trow] : 0.0f));
+                const float advr = cur.adv;
+                const float ratio = expf(lp_a - cur.olp);
                 const float lo = 1.0f - p.eps_clip, hi = 1.0f + p.eps_clip;
                 const float surr1 = ratio * advr, surr2 = fminf(fmaxf(ratio, lo), hi) * advr;
                 const float inrange = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
@@ -264,11 +340,14 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
                     z[t][r] = j < A ? scale * dz : 0.0f;  // d3
                 }
             // dW3 += d3 (x) relu(h2)
+            PST(3);
             wave_sync();
             put_tile<T3>(Td, z, lane, [](int, int, float x) { return x; });
             put_tile<2>(Ta, h2, lane, [](int, int, float x) { return relu(x); });
             wave_sync();
+            PST(4);
             wgrad<T3, 2>(gW3, gb3, Td, Ta, lane);
+            PST(5);
             // d2 = (W3^T d3) .* [h2 > 0]
             acc_zero<2>(d2);
             chain<2, T3>(d2, s_f3t, z, lane, [](int, int, float x) { return x; });
@@ -299,7 +378,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             } else {
                 if (ok && half == 0 && p.out_a) p.out_a[row] = v;
                 if (!p.target) continue;  // forward only
-                const float err = (v - (ok ? p.target[trow] : 0.0f)) * m;
+                const float err = (v - cur.tgt) * m;
                 if (half == 0) loss_acc = fmaf(err * err, p.inv_denom, loss_acc);
                 if (!backward) continue;
                 dv = 2.0f * err * m * p.inv_denom;
@@ -326,11 +405,14 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
                 for (int r = 0; r < 16; r++) d2[t][r] = h2[t][r] > 0.0f ? d2[t][r] : 0.0f;
         }
         // dW2 += d2 (x) relu(h1)
+        PST(6);
         wave_sync();
         put_tile<2>(Td, d2, lane, [](int, int, float x) { return x; });
         put_tile<2>(Ta, h1, lane, [](int, int, float x) { return relu(x); });
         wave_sync();
+        PST(4);
         wgrad<2, 2>(gW2, gb2, Td, Ta, lane);
+        PST(5);
         // d1 = (W2^T d2) .* [h1 > 0]
         f32x16 d1[2];
         acc_zero<2>(d1);
@@ -340,13 +422,21 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) d1[t][r] = h1[t][r] > 0.0f ? d1[t][r] : 0.0f;
         // dW1 += d1 (x) (obs | one-hot agent id)
+        PST(7);
         wave_sync();
         put_tile<2>(Td, d1, lane, [](int, int, float x) { return x; });
         for (int in = half; in < 32 * IN1T; in += 2)
-            Ta[in * TS + jrow] = in < OBS ? s_obs[jrow * OBS + in] : ((ok && N > 0 && in - OBS == agent) ? 1.0f : 0.0f);
+            Ta[in * TSTR + jrow] = in < OBS ? s_obs[jrow * OBS + in] : ((ok && N > 0 && in - OBS == agent) ? 1.0f : 0.0f);
         wave_sync();
+        PST(4);
         wgrad<2, IN1T>(gW1, gb1, Td, Ta, lane);
+        PST(5);
     }
+#ifdef ABL_PPO_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0 && BWD && n_tiles > 10000)
+        printf("k_ppo<head %d> cycles per section, wave 0 of block 0: load %llu | fwd L1+L2 %llu | L3 %llu | head %llu | put %llu | "
+               "wgrad %llu | chain d2 %llu | chain d1 %llu\n", HEAD, pst[0], pst[1], pst[2], pst[3], pst[4], pst[5], pst[6], pst[7]);
+#endif
 
     // ------------------------------------------------------------------ flush this wave's partial sums
     if (p.loss) {  // one atomic per wave: 32 lanes adding to the same word serialise at the memory side
@@ -406,7 +496,7 @@ size_t ppo_lds_bytes(int head, int TO3, int N, int A, int nw, bool bwd) {
     size_t f = 8 * 2 * 64 + 2 * (32 * 2 * 64);
     f += head == 0 ? (size_t)32 * TO3 * 64 + (size_t)16 * TO3 * 2 * 64 : 64;
     f += 2 * H + 32 * (head == 0 ? TO3 : 1) + (size_t)N * H;
-    const size_t per_wave = 32 * OBS + 4 + (head == 0 ? 32 * A : 0) + (bwd ? 2 * 64 * TS : 0);  // transposition tiles
+    const size_t per_wave = 32 * OBS + 4 + (head == 0 ? 32 * A : 0) + (bwd ? 2 * TILE : 0);  // transposition tiles
     return sizeof(float) * (f + nw * per_wave);
 }
 
