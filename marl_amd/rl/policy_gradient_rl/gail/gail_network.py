@@ -41,6 +41,131 @@ class Critic(_ActorCritic):
         super().__init__(args, 1)
 
 
+class _TallBatchNormFn(th.autograd.Function):
+    """Training-mode BatchNorm1d over [rows, C] for inputs beyond 2^31 elements, out of column reductions and fused
+    multiply-adds.  torch's own backward (batch_norm_backward_reduce_kernel with 64-bit indexing) takes 1.8 s per call on
+    [32.8 M, 128] on MI355X -- 7 s of GAIL's update at BASELINE configs[4] (65.5 M rows).  Same arithmetic as
+    F.batch_norm(training=True): biased variance for the normalisation, the exact backward through mean and variance."""
+
+    CHUNK = 1 << 22  # rows per reduction chunk (bounds the elementwise temporaries)
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        var, mean = th.var_mean(x, dim=0, unbiased=False)
+        invstd = th.rsqrt(var + eps)
+        scale = invstd * weight
+        y = th.addcmul(bias - mean * scale, x, scale)
+        ctx.save_for_backward(x, weight, mean, invstd)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dmean, _dvar):
+        x, weight, mean, invstd = ctx.saved_tensors
+        n = x.shape[0]
+        s1 = th.zeros_like(mean)
+        s2 = th.zeros_like(mean)
+        for lo in range(0, n, _TallBatchNormFn.CHUNK):
+            d, xc = dy[lo:lo + _TallBatchNormFn.CHUNK], x[lo:lo + _TallBatchNormFn.CHUNK]
+            s1 += d.sum(0)
+            s2 += (d * xc).sum(0)
+        s2 = (s2 - mean * s1) * invstd                 # sum dy * xhat
+        a = weight * invstd
+        b = -a * invstd * s2 / n
+        c = -a * s1 / n - b * mean
+        dx = th.addcmul(th.addcmul(c, dy, a), x, b)    # w * invstd * (dy - mean(dy) - xhat * mean(dy * xhat))
+        return dx, s2, s1, None
+
+
+def _keep_mask(x, p):
+    """bool [rows, C]: bernoulli(1 - p) per element, drawn in row chunks (no [rows, C] fp32 temporary)"""
+    keep = th.empty(x.shape, dtype=th.bool, device=x.device)
+    step = _TallBatchNormFn.CHUNK
+    for lo in range(0, x.shape[0], step):
+        th.ge(th.rand(x[lo:lo + step].shape, device=x.device), p, out=keep[lo:lo + step])
+    return keep
+
+
+class _TallBnReluDropFn(th.autograd.Function):
+    """BatchNorm1d (training) -> ReLU -> Dropout(p) of one discriminator layer as ONE autograd node for tall inputs:
+    keeps the pre-BN input and a one-byte keep mask instead of the four [rows, C] fp32 tensors the separate modules
+    save (at 65.5 M rows x 128 that is the difference between fitting 288 GB with room and the allocator thrashing)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, p):
+        var, mean = th.var_mean(x, dim=0, unbiased=False)
+        invstd = th.rsqrt(var + eps)
+        scale = invstd * weight
+        shift = bias - mean * scale
+        keep = _keep_mask(x, p)                           # bernoulli(1 - p), as F.dropout draws it
+        out = th.addcmul(shift, x, scale).clamp_(min=0).mul_(keep).mul_(1.0 / (1.0 - p))
+        ctx.save_for_backward(x, keep, weight, mean, invstd, shift)
+        ctx.p = p
+        ctx.mark_non_differentiable(mean, var)
+        return out, mean, var
+
+    @staticmethod
+    def backward(ctx, dout, _dmean, _dvar):
+        x, keep, weight, mean, invstd, shift = ctx.saved_tensors
+        n, C = x.shape
+        scale = invstd * weight
+        inv_keep = 1.0 / (1.0 - ctx.p)
+        step = _TallBatchNormFn.CHUNK
+
+        def dy_chunk(lo):  # d loss / d (BN output) of the rows [lo, lo + step): through dropout and ReLU
+            xc = x[lo:lo + step]
+            live = keep[lo:lo + step] & (th.addcmul(shift, xc, scale) > 0)
+            return dout[lo:lo + step] * live * inv_keep, xc
+        s1 = th.zeros_like(mean)
+        s2 = th.zeros_like(mean)
+        for lo in range(0, n, step):
+            d, xc = dy_chunk(lo)
+            s1 += d.sum(0)
+            s2 += (d * xc).sum(0)
+        s2 = (s2 - mean * s1) * invstd
+        a = weight * invstd
+        b = -a * invstd * s2 / n
+        c = -a * s1 / n - b * mean
+        dx = th.empty_like(x)
+        for lo in range(0, n, step):
+            d, xc = dy_chunk(lo)
+            th.addcmul(th.addcmul(c, d, a), xc, b, out=dx[lo:lo + step])
+        return dx, s2, s1, None, None
+
+
+class TallBatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d (same parameters, buffers and state_dict keys); training-mode inputs of TALL_NUMEL elements or
+    more take _TallBatchNormFn."""
+
+    TALL_NUMEL = 1 << 30
+
+    def forward(self, x):
+        if not self.tall(x):
+            return super().forward(x)
+        y, mean, var = _TallBatchNormFn.apply(x, self.weight, self.bias, self.eps)
+        self._track(x.shape[0], mean, var)
+        return y
+
+    def relu_dropout(self, x, p):
+        """dropout(relu(self(x)), p) for a tall training-mode input, as one autograd node"""
+        y, mean, var = _TallBnReluDropFn.apply(x, self.weight, self.bias, self.eps, float(p))
+        self._track(x.shape[0], mean, var)
+        return y
+
+    def tall(self, x):
+        return self.training and x.dim() == 2 and x.numel() >= self.TALL_NUMEL
+
+    def _track(self, n, mean, var):
+        if self.track_running_stats:
+            with th.no_grad():
+                self.num_batches_tracked.data += 1
+                m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                # (through .data: torch's own batch_norm saves the running statistics for its backward, and an earlier
+                # call of this module on a small batch -- GAIL's 64 expert rows -- may still be waiting for it)
+                self.running_mean.data.mul_(1 - m).add_(mean, alpha=m)
+                self.running_var.data.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+
+
 class Discriminator(nn.Module):
     """gail_network.py:59-132: (obs | agent id | one-hot action) -> 2H -> H -> H/2 -> 1 logit, each hidden layer
     Linear -> BatchNorm (skipped for a single row) -> activation -> Dropout; Xavier-uniform weights, zero biases."""
@@ -52,7 +177,7 @@ class Discriminator(nn.Module):
         widths = (args.obs_shape + args.n_agents + args.n_actions, h * 2, h, h // 2)
         for i, p in enumerate((0.3, 0.3, 0.2), start=1):
             setattr(self, "fc%d" % i, SplitKLinear(widths[i - 1], widths[i]))   # tall-batch weight gradients
-            setattr(self, "bn%d" % i, nn.BatchNorm1d(widths[i]))
+            setattr(self, "bn%d" % i, TallBatchNorm1d(widths[i]))
             setattr(self, "dropout%d" % i, nn.Dropout(p))
         self.fc4 = nn.Linear(widths[3], 1)
         self.activate_func = _act(args, ("relu", "tanh", "leaky_relu"))
@@ -66,8 +191,12 @@ class Discriminator(nn.Module):
         x = th.cat([obs.reshape(-1, obs.shape[-1]), actions.reshape(-1, actions.shape[-1])], dim=-1)
         for i in (1, 2, 3):
             x = getattr(self, "fc%d" % i)(x)
+            bn, drop = getattr(self, "bn%d" % i), getattr(self, "dropout%d" % i)
+            if bn.tall(x) and drop.training and self.activate_func is F.relu:
+                x = bn.relu_dropout(x, drop.p)      # one autograd node for the layer's tail (memory at 10^7..10^8 rows)
+                continue
             if x.shape[0] > 1:
-                x = getattr(self, "bn%d" % i)(x)
-            x = getattr(self, "dropout%d" % i)(self.activate_func(x))
+                x = bn(x)
+            x = drop(self.activate_func(x))
         x = self.fc4(x)
         return x.view(*lead, 1) if len(lead) > 1 else x

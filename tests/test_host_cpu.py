@@ -411,3 +411,65 @@ def test_splitk_linear_and_select_embedding_match_stock_autograd():
     lb.mean().backward()
     for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         assert th.allclose(p.grad, q.grad, rtol=1e-8, atol=1e-11), k
+
+
+def test_tall_batchnorm_matches_stock():
+    """gail_network.TallBatchNorm1d's large-input path (column reductions + fused multiply-adds) against nn.BatchNorm1d:
+    outputs, input / weight / bias gradients and running statistics."""
+    import torch as th
+    from marl_amd.rl.policy_gradient_rl.gail.gail_network import TallBatchNorm1d, _TallBatchNormFn
+    th.manual_seed(5)
+    rows, C = 1000, 24
+    x = (th.randn(rows, C) * th.linspace(0.5, 3.0, C) + th.linspace(-2, 2, C)).double()
+    g = th.randn(rows, C).double()
+    stock, tall = th.nn.BatchNorm1d(C).double(), TallBatchNorm1d(C).double()
+    with th.no_grad():
+        for m in (stock, tall):
+            m.weight.copy_(th.linspace(0.5, 1.5, C))
+            m.bias.copy_(th.linspace(-1, 1, C))
+    old_numel, old_chunk = TallBatchNorm1d.TALL_NUMEL, _TallBatchNormFn.CHUNK
+    TallBatchNorm1d.TALL_NUMEL, _TallBatchNormFn.CHUNK = 0, 300   # force the path, several reduction chunks
+    try:
+        outs = []
+        for m in (stock, tall):
+            xi = x.clone().requires_grad_(True)
+            for _ in range(2):  # two calls: running statistics and num_batches_tracked advance alike
+                y = m(xi)
+            (y * g).sum().backward()
+            outs.append((y.detach(), xi.grad, m.weight.grad, m.bias.grad, m.running_mean, m.running_var,
+                         m.num_batches_tracked))
+    finally:
+        TallBatchNorm1d.TALL_NUMEL, _TallBatchNormFn.CHUNK = old_numel, old_chunk
+    for a, b in zip(*outs):
+        assert th.allclose(a.double(), b.double(), rtol=1e-10, atol=1e-11), (a - b).abs().max()
+    # below the threshold it IS the stock module
+    assert th.equal(tall.eval()(x), th.nn.functional.batch_norm(x, tall.running_mean, tall.running_var, tall.weight, tall.bias,
+                                                               False, 0.1, tall.eps))
+
+
+def test_tall_bn_relu_dropout_node_matches_modules(monkeypatch):
+    """The one-node BatchNorm -> ReLU -> Dropout of the GAIL discriminator's tall-input path against the three stock
+    modules on the same keep mask: output, input / weight / bias gradients, running statistics."""
+    import torch as th
+    import marl_amd.rl.policy_gradient_rl.gail.gail_network as gn
+    th.manual_seed(6)
+    rows, C, p = 900, 16, 0.3
+    x = (th.randn(rows, C) * 2 + th.linspace(-1, 1, C)).double()
+    g = th.randn(rows, C).double()
+    mask = th.rand(rows, C) >= p
+    monkeypatch.setattr(gn, "_keep_mask", lambda x_, p_: mask)
+    monkeypatch.setattr(gn._TallBatchNormFn, "CHUNK", 256)
+    stock, tall = th.nn.BatchNorm1d(C).double(), gn.TallBatchNorm1d(C).double()
+    with th.no_grad():
+        for m in (stock, tall):
+            m.weight.copy_(th.linspace(0.5, 1.5, C))
+            m.bias.copy_(th.linspace(-0.5, 0.5, C))
+    xa = x.clone().requires_grad_(True)
+    out_a = th.relu(stock(xa)) * mask / (1 - p)
+    (out_a * g).sum().backward()
+    xb = x.clone().requires_grad_(True)
+    out_b = tall.relu_dropout(xb, p)
+    (out_b * g).sum().backward()
+    for a, b in ((out_a, out_b), (xa.grad, xb.grad), (stock.weight.grad, tall.weight.grad), (stock.bias.grad, tall.bias.grad),
+                 (stock.running_mean, tall.running_mean), (stock.running_var, tall.running_var)):
+        assert th.allclose(a.detach(), b.detach(), rtol=1e-10, atol=1e-11), (a - b).abs().max()

@@ -64,7 +64,9 @@ def main():
            "train_ms": 1e3 * med(spans[1:]) if len(spans) > 1 else None,
            "rollout_ms": 1e3 * (med(tot[1:]) - (med(spans[1:]) if len(spans) > 1 else 0.0)),
            "first_iteration_ms": 1e3 * tot[0], "success_rate": info["success_rate"],
-           "expert_buffer": len(agent.expert_transitions)}
+           "expert_buffer": len(agent.expert_transitions),
+           "max_memory_allocated_gb": th.cuda.max_memory_allocated() / 2**30,
+           "max_memory_reserved_gb": th.cuda.max_memory_reserved() / 2**30}
     print(json.dumps(out), flush=True)
     runner.close_env()
 
