@@ -309,8 +309,8 @@ int launch_diff(const DiffArgs& a, hipStream_t stream) {
     const int SA = OBS + a.A;
     int nw = 4;
     size_t lds = diff_lds_bytes(TX, SA, nw, BWD);
-    if (lds > DIFF_LDS_MAX) {
-        nw = 2;
+    for (int w = 3; w >= 2 && lds > DIFF_LDS_MAX; w--) {  // fewer waves per block until the per-wave tiles fit
+        nw = w;
         lds = diff_lds_bytes(TX, SA, nw, BWD);
     }
     if (lds > DIFF_LDS_MAX) return ec::fail(EC_EINVAL, "ec_diffusion_grad: LDS need %zu too large", lds);

@@ -505,8 +505,8 @@ int launch_ppo(const PpoArgs& a, hipStream_t stream) {
     int nw = 4;
     const bool bwd = a.grads != nullptr;
     size_t lds = ppo_lds_bytes(HEAD, TO3, a.n_agents, a.A, nw, bwd);
-    if (lds > PPO_LDS_MAX) {
-        nw = 2;
+    for (int w = 3; w >= 2 && lds > PPO_LDS_MAX; w--) {  // fewer waves per block until the per-wave tiles fit
+        nw = w;
         lds = ppo_lds_bytes(HEAD, TO3, a.n_agents, a.A, nw, bwd);
     }
     if (lds > PPO_LDS_MAX) return ec::fail(EC_EINVAL, "ec_ppo: %d agents need %zu B of LDS", a.n_agents, lds);
