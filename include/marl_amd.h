@@ -365,6 +365,18 @@ int ec_gail_disc_grad(const float* w1, const float* b1, const float* w2, const f
                       const float* obs, const int64_t* actions, int64_t rows, int32_t n_actions, int32_t hidden,
                       int32_t expert, float inv_denom, float* grads, float* loss, float* prob, void* stream);
 
+/* Expert mixing of the guided runners, one env step: replaces the per-env coin test, the action select and the append of
+ * expert-driven envs' (observation, expert action) to the FIFO of expert transitions (gail_runner.py:72-98,
+ * dgail_runner.py:46-94, gail_agent.py:77-83 / dgail_agent.py:135-149).
+ *   env b is expert-driven iff coin[b] < *ratio (ratio: device scalar);  exec_actions[b] = expert or agent actions;
+ *   selected envs, in env order, go to ring slots (*written + rank) % capacity of ring_obs [capacity(+),N,O] /
+ *   ring_actions [capacity(+),N]; when one call selects more than `capacity` envs the newest `capacity` are kept;
+ *   *written += number selected;  *n_expert (optional) += the same.  Two launches, no host synchronisation. */
+int ec_expert_mix(const float* coin, const float* ratio, const int64_t* expert_actions, const int64_t* agent_actions,
+                  const float* obs, int64_t n_envs, int32_t n_agents, int32_t obs_dim, int64_t capacity,
+                  int64_t* exec_actions, float* ring_obs, int64_t* ring_actions, int64_t* written, int64_t* n_expert,
+                  void* stream);
+
 const char* ec_last_error(void);
 const char* ec_version(void);
 

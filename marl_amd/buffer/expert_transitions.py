@@ -51,6 +51,27 @@ class ExpertTransitions:
         self.actions.index_copy_(0, slot, actions.to(self.device, th.int64))
         self._written += n_sel
 
+    def mix_append(self, coin, ratio, expert_actions, agent_actions, obs, n_expert=None):
+        """One step of the guided runners on the device (ec_expert_mix): env b executes the expert's action iff
+        coin[b] < ratio (a device scalar) and then appends (obs[b], expert_actions[b]) as append() would; returns the
+        actions to execute [B,N]; n_expert (device int64 scalar, optional) += the number of expert-driven envs."""
+        import ctypes as C
+
+        from marl_amd import _abi
+        B, N, O = obs.shape
+        expert_actions = expert_actions.to(th.int64).contiguous()
+        agent_actions = agent_actions.to(th.int64).contiguous()
+        obs = obs.to(th.float32).contiguous()
+        coin = coin.to(th.float32).contiguous()
+        out = th.empty_like(agent_actions)
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        with th.cuda.device(self.device):
+            _abi.check(_abi.lib().ec_expert_mix(vp(coin), vp(ratio), vp(expert_actions), vp(agent_actions), vp(obs), B, N, O,
+                                                self.capacity, vp(out), vp(self.obs), vp(self.actions), vp(self._written),
+                                                vp(n_expert), C.c_void_p(th.cuda.current_stream(self.device).cuda_stream)),
+                       "ec_expert_mix")
+        return out
+
     def sample_transitions(self, n):
         """n distinct transitions, uniformly (np.random.choice(len, n, replace=False) of the reference):
         returns obs [n,N,O], actions [n,N]."""

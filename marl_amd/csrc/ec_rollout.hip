@@ -295,3 +295,115 @@ extern "C" int ec_store_transition(const float* obs, const int32_t* avail, const
     EC_HIP(hipGetLastError());
     return EC_OK;
 }
+
+// ------------------------------------------------------------------------------------------ expert mixing
+// Per step of the expert-guided runners (gail_runner.py:72-98, dgail_runner.py:46-94): the per-env coin decides whether an
+// env executes the expert's or the agent's action, and expert-driven envs append (obs, expert action) to the agent's
+// FIFO of expert transitions (gail_agent.py:77-83).  In torch: compare, where, cumsum, sum, index arithmetic and two
+// index_copy_ per step (~17 launches); here two.
+namespace {
+
+struct MixArgs {
+    const float* coin;    // [B] uniform draws
+    const float* ratio;   // device scalar: expert iff coin < ratio
+    const int64_t* expert_actions;  // [B,N]
+    const int64_t* agent_actions;   // [B,N]
+    const float* obs;     // [B,N,O]
+    int64_t B;
+    int N, O;
+    int64_t capacity;
+    int64_t* exec_actions;  // [B,N]
+    float* ring_obs;        // [>= capacity, N, O]
+    int64_t* ring_actions;  // [>= capacity, N]
+    int64_t* written;       // device scalar: transitions ever appended
+    int64_t* n_expert;      // device scalar (optional): expert-driven env steps so far
+};
+
+constexpr int MIX_EPB = 16;  // envs per block
+
+__device__ __forceinline__ int64_t block_sum(int64_t v, int64_t* s_red) {
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int64_t t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += s_red[w];
+    return t;
+}
+
+// Envs [b0, b0 + MIX_EPB) of the block: the rank of a selected env among all selected ones is the count of selected
+// envs before it, which every block counts for itself from the B coins (L2-resident).  The FIFO keeps the newest
+// `capacity` of one call's rows, as appending them one by one would (ExpertTransitions.append).
+__global__ void __launch_bounds__(256) k_expert_mix(MixArgs a) {
+    __shared__ int64_t s_red[4];
+    __shared__ int64_t s_slot[MIX_EPB];
+    const float ratio = *a.ratio;
+    const int64_t b0 = (int64_t)blockIdx.x * MIX_EPB;
+    int64_t before = 0, total = 0;
+    for (int64_t b = threadIdx.x; b < a.B; b += blockDim.x) {
+        const int64_t u = a.coin[b] < ratio ? 1 : 0;
+        total += u;
+        before += b < b0 ? u : 0;
+    }
+    total = block_sum(total, s_red);
+    before = block_sum(before, s_red);
+    const int64_t written = *a.written;
+    if (threadIdx.x == 0) {
+        int64_t rank = before;
+        for (int e = 0; e < MIX_EPB; e++) {
+            const int64_t b = b0 + e;
+            const bool use = b < a.B && a.coin[b] < ratio;
+            s_slot[e] = (use && rank >= total - a.capacity) ? (written + rank) % a.capacity : (use ? -2 : -1);
+            rank += use ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    const int64_t nb = a.B - b0 < MIX_EPB ? a.B - b0 : MIX_EPB;
+    for (int i = threadIdx.x; i < (int)nb * a.N; i += blockDim.x) {
+        const int e = i / a.N, n = i - e * a.N;
+        const int64_t src = (b0 + e) * a.N + n, slot = s_slot[e];
+        const int64_t ex = a.expert_actions[src];
+        a.exec_actions[src] = slot != -1 ? ex : a.agent_actions[src];
+        if (slot >= 0) a.ring_actions[slot * a.N + n] = ex;
+    }
+    const int row = a.N * a.O;
+    for (int i = threadIdx.x; i < (int)nb * row; i += blockDim.x) {
+        const int e = i / row, k = i - e * row;
+        const int64_t slot = s_slot[e];
+        if (slot >= 0) a.ring_obs[slot * row + k] = a.obs[(b0 + e) * row + k];
+    }
+}
+
+// after every block of k_expert_mix has read `written`: advance the counters
+__global__ void __launch_bounds__(256) k_expert_mix_count(MixArgs a) {
+    __shared__ int64_t s_red[4];
+    const float ratio = *a.ratio;
+    int64_t total = 0;
+    for (int64_t b = threadIdx.x; b < a.B; b += blockDim.x) total += a.coin[b] < ratio ? 1 : 0;
+    total = block_sum(total, s_red);
+    if (threadIdx.x == 0) {
+        *a.written += total;
+        if (a.n_expert) *a.n_expert += total;
+    }
+}
+
+}  // namespace
+
+extern "C" int ec_expert_mix(const float* coin, const float* ratio, const int64_t* expert_actions, const int64_t* agent_actions,
+                             const float* obs, int64_t n_envs, int32_t n_agents, int32_t obs_dim, int64_t capacity,
+                             int64_t* exec_actions, float* ring_obs, int64_t* ring_actions, int64_t* written,
+                             int64_t* n_expert, void* stream) {
+    if (n_envs == 0) return EC_OK;
+    if (!coin || !ratio || !expert_actions || !agent_actions || !obs || !exec_actions || !ring_obs || !ring_actions || !written)
+        return ec::fail(EC_EINVAL, "ec_expert_mix: null pointer");
+    if (n_envs < 0 || n_agents < 1 || obs_dim < 1 || capacity < 1)
+        return ec::fail(EC_EINVAL, "ec_expert_mix: n_envs %lld, n_agents %d, obs_dim %d, capacity %lld", (long long)n_envs,
+                        n_agents, obs_dim, (long long)capacity);
+    MixArgs a{coin, ratio, expert_actions, agent_actions, obs, n_envs, n_agents, obs_dim, capacity, exec_actions, ring_obs,
+              ring_actions, written, n_expert};
+    const int64_t blocks = (n_envs + MIX_EPB - 1) / MIX_EPB;
+    hipLaunchKernelGGL(k_expert_mix, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_expert_mix_count, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}

@@ -98,16 +98,21 @@ class DGAILRunner:
                 self._obs.copy_(env.obs)
                 self._avail.copy_(env.avail)
                 obs, avail = self._obs, self._avail
-            # bool [B]: which envs act on the expert this step (dgail_runner.py:46)
-            use_expert = None if test_mode else th.rand(B, device=env.device) < self._ratios[t]
             agent_actions = self.agent.select_actions(obs, avail, test_mode)
-            if use_expert is not None:
+            if test_mode:
+                exec_actions = agent_actions
+            elif env.device.type == "cuda":
+                # the coin (dgail_runner.py:46), the action select and the FIFO append (:93-94, before the step: obs is
+                # the pre-step one) in two launches (ec_expert_mix) instead of ~17
+                exec_actions = self.agent.expert_transitions.mix_append(
+                    th.rand(B, device=env.device), self._ratios[t:t + 1], self.agent.get_expert_actions(env), agent_actions,
+                    obs, n_expert)
+            else:
+                use_expert = th.rand(B, device=env.device) < self._ratios[t]   # bool [B]
                 expert_actions = self.agent.get_expert_actions(env)
                 exec_actions = th.where(use_expert.unsqueeze(-1), expert_actions, agent_actions)
                 n_expert += use_expert.sum()
-                self.agent.store_expert_data(obs, expert_actions, use_expert)     # :93-94 (before the step: obs is pre-step)
-            else:
-                exec_actions = agent_actions
+                self.agent.store_expert_data(obs, expert_actions, use_expert)
             reward, terminated, info = env.step(exec_actions, want_hops=(t == args.episode_limit - 1))
             if fast:
                 self._store.step(t, agent_actions, reward, terminated, info, buf)   # the buffer keeps the AGENT's action, :81

@@ -75,7 +75,12 @@ class GAILRunner:
                 self._avail.copy_(env.avail)
                 obs, avail = self._obs, self._avail
             agent_actions = self.agent.select_actions(obs, avail, test_mode)
-            if guided:
+            if guided and env.device.type == "cuda":
+                # coin, select and FIFO append in two launches (ec_expert_mix) instead of ~17
+                exec_actions = self.agent.expert_transitions.mix_append(
+                    th.rand(B, device=env.device), self._ratio.reshape(1), self.agent.get_expert_actions(env), agent_actions,
+                    obs)
+            elif guided:
                 use_expert = th.rand(B, device=env.device) < self._ratio
                 expert_actions = self.agent.get_expert_actions(env)
                 exec_actions = th.where(use_expert.unsqueeze(-1), expert_actions, agent_actions)

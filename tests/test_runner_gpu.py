@@ -616,3 +616,33 @@ def test_main_driver_trains_tests_and_checkpoints(tmp_path, monkeypatch):
     res = driver.main(["--name=ppo", "--task_size_max=6000", "--n_threads=16", "--episode_limit=20", "--test_nepisode=32",
                        "--test_models=1", "--load_models=1", "--folder=t", "--checkpoint_path=" + out["run"]])
     assert 0.0 <= res["success_rate"] <= 1.0 and abs(res["success_rate"] + res["drop_rate"] + res["failure_rate"] - 1) < 1e-9
+
+
+@pytest.mark.parametrize("B,cap,ratio", [(64, 1000, 0.5), (700, 100, 0.9), (4096, 1000, 1.0), (33, 50, 0.0), (1, 5, 1.0)])
+def test_expert_mix_equals_torch_append(B, cap, ratio):
+    """ec_expert_mix (coin, action select, FIFO append of the guided runners: gail_runner.py:72-98, gail_agent.py:77-83)
+    against the torch formulation (rand < ratio, th.where, ExpertTransitions.append), over several steps so that the
+    ring wraps; B > capacity keeps the newest rows.  Bit-exact: ring contents, counters, executed actions."""
+    import torch as th
+    from marl_amd.buffer.expert_transitions import ExpertTransitions
+    dev = th.device("cuda")
+    N, O, A = 10, 9, 11
+    g = th.Generator().manual_seed(B + cap)
+    ref, got = ExpertTransitions(cap, N, O, dev), ExpertTransitions(cap, N, O, dev)
+    n_ref, n_got = th.zeros((), dtype=th.int64, device=dev), th.zeros((), dtype=th.int64, device=dev)
+    r = th.tensor([ratio], dtype=th.float32, device=dev)
+    for step in range(7):
+        coin = th.rand(B, generator=g).to(dev)
+        obs = th.rand(B, N, O, generator=g).to(dev)
+        ea = th.randint(0, A, (B, N), generator=g).to(dev)
+        aa = th.randint(0, A, (B, N), generator=g).to(dev)
+        use = coin < r
+        want_exec = th.where(use.unsqueeze(-1), ea, aa)
+        ref.append(obs, ea, use)
+        n_ref += use.sum()
+        got_exec = got.mix_append(coin, r, ea, aa, obs, n_got)
+        assert th.equal(got_exec, want_exec), step
+        assert int(got._written) == int(ref._written) and int(n_got) == int(n_ref), step
+        k = len(ref)
+        assert len(got) == k
+        assert th.equal(got.obs[:cap], ref.obs[:cap]) and th.equal(got.actions[:cap], ref.actions[:cap]), step
