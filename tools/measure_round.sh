@@ -17,4 +17,6 @@ timeout -k 10 200 python tools/bench_imitation.py --algo gail --envs 4096 >> $O/
 timeout -k 10 200 python tools/bench_imitation.py --algo dgail --envs 4096 >> $O/imitation_$TAG.jsonl 2>$O/imit.err || { tail -5 $O/imit.err; exit 1; }
 timeout -k 10 200 python tools/bench_imitation.py --algo dgail --envs 4096 --diffusion-reward >> $O/imitation_$TAG.jsonl 2>$O/imit.err || { tail -5 $O/imit.err; exit 1; }
 timeout -k 10 200 python tools/bench_imitation.py --algo dgail --envs 1024 >> $O/imitation_$TAG.jsonl 2>$O/imit.err || { tail -5 $O/imit.err; exit 1; }
+timeout -k 10 250 python tools/bench_imitation.py --algo gail --envs 2048 --nodes 40 >> $O/imitation_$TAG.jsonl 2>$O/imit.err || { tail -5 $O/imit.err; exit 1; }
+timeout -k 10 400 python tools/bench_imitation.py --algo gail --envs 16384 --nodes 40 --iters 4 >> $O/imitation_$TAG.jsonl 2>$O/imit.err || { tail -5 $O/imit.err; exit 1; }
 cat $O/imitation_$TAG.jsonl
