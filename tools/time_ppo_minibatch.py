@@ -49,3 +49,17 @@ for n in sizes:
                                               loss=losses[1:2], row_index=idx))
     tiles = (n + 31) // 32
     print("rows %8d  tiles/wave %6.1f  actor %8.1f us  critic %8.1f us" % (n, tiles / 1024.0, ta, tc))
+
+# the diffusion discriminator's compute_loss call at the largest size (ec_diffusion_grad: forward only / forward + backward)
+from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import DiffusionDiscriminator  # noqa: E402
+from marl_amd.utils import mlp_device  # noqa: E402
+
+n = max(sizes)
+disc = DiffusionDiscriminator(9 + A, 64).to(dev)
+t = th.randint(0, 2, (n,), device=dev)
+noise = th.randn(n, 9 + A, device=dev)
+coef = th.randn(n, device=dev) / n
+call = mlp_device.DiffusionLossCall(disc, 1, obs[:n], act[:n], A, t, noise)
+tf = timed(lambda: call.loss(), reps=10)
+tb = timed(lambda: call.backward(coef), reps=10)
+print("rows %8d  k_diff forward %8.1f us  forward+backward %8.1f us" % (n, tf, tb))
