@@ -253,6 +253,24 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
         wgrad<2, TX>(gW1, gb1, Td, Ta, lane);
     }
 
+    if (BWD && nw > 1) {  // wave 0 collects the block's sums and is the only one to flush them (see block_sum)
+        block_sum(gW2, lds, wave, nw, lane);
+        block_sum(gW1, lds, wave, nw, lane);
+        block_sum(gW3, lds, wave, nw, lane);
+        f32x16 ws[1][2] = {{gw3s[0], gw3s[1]}};
+        block_sum(ws, lds, wave, nw, lane);
+        gw3s[0] = ws[0][0];
+        gw3s[1] = ws[0][1];
+        float sc[6] = {gb1[0], gb1[1], gb2[0], gb2[1], gb3[0], TX > 1 ? gb3[TX - 1] : 0.0f};
+        block_sum_scalars(sc, lds, wave, nw, lane);
+        gb1[0] = sc[0];
+        gb1[1] = sc[1];
+        gb2[0] = sc[2];
+        gb2[1] = sc[3];
+        gb3[0] = sc[4];
+        if (TX > 1) gb3[TX - 1] = sc[5];
+        if (wave > 0) return;
+    }
     if (BWD) {
         float* gW1p = p.grads;
         float* gbp = gW1p + (size_t)H * SA;

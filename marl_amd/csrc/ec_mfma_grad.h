@@ -91,6 +91,48 @@ __device__ __forceinline__ void wgrad(f32x16 (&acc)[TO][TI], float (&dbias)[TO],
     }
 }
 
+// Sum the block's waves' accumulators into wave 0 through LDS (`buf`: at least (nw - 1) * TA * TB * 1024 floats that no
+// wave uses any more).  Every wave of a pass ends with the same ~6 k gradient words to add to: one wave per block doing
+// the atomics instead of four is a quarter of the memory-side atomic traffic.
+template <int TA, int TB>
+__device__ __forceinline__ void block_sum(f32x16 (&acc)[TA][TB], float* __restrict__ buf, int wave, int nw, int lane) {
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int a = 0; a < TA; a++)
+#pragma unroll
+            for (int b = 0; b < TB; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) buf[((((wave - 1) * TA + a) * TB + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < nw; w++) {
+#pragma unroll
+            for (int a = 0; a < TA; a++)
+#pragma unroll
+                for (int b = 0; b < TB; b++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[a][b][r] += buf[((((w - 1) * TA + a) * TB + b) * 16 + r) * 64 + lane];
+        }
+    }
+}
+template <int NS>
+__device__ __forceinline__ void block_sum_scalars(float (&v)[NS], float* __restrict__ buf, int wave, int nw, int lane) {
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) buf[((wave - 1) * NS + i) * 64 + lane] = v[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < nw; w++) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) v[i] += buf[((w - 1) * NS + i) * 64 + lane];
+        }
+    }
+}
+
 // flush an accumulator tile pair into a row-major [n_out][ld] gradient with atomics
 template <int TO, int TI>
 __device__ __forceinline__ void flush(float* __restrict__ g, int ld, int n_out, int n_in, const f32x16 (&acc)[TO][TI], int lane) {

@@ -438,7 +438,23 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
                "wgrad %llu | chain d2 %llu | chain d1 %llu\n", HEAD, pst[0], pst[1], pst[2], pst[3], pst[4], pst[5], pst[6], pst[7]);
 #endif
 
-    // ------------------------------------------------------------------ flush this wave's partial sums
+    // ------------------------------------------------------------------ flush the partial sums
+    if (backward && nw > 1) {  // wave 0 collects the block's sums and is the only one to flush them
+        block_sum(gW2, lds, wave, nw, lane);
+        block_sum(gW1, lds, wave, nw, lane);
+        block_sum(gW3, lds, wave, nw, lane);
+        float sc[8] = {gb1[0], gb1[1], gb2[0], gb2[1], gb3[0], T3 > 1 ? gb3[T3 - 1] : 0.0f, gb3c, loss_acc};
+        block_sum_scalars(sc, lds, wave, nw, lane);
+        gb1[0] = sc[0];
+        gb1[1] = sc[1];
+        gb2[0] = sc[2];
+        gb2[1] = sc[3];
+        gb3[0] = sc[4];
+        if (T3 > 1) gb3[T3 - 1] = sc[5];
+        gb3c = sc[6];
+        loss_acc = sc[7];
+        if (wave > 0) return;
+    }
     if (p.loss) {  // one atomic per wave: 32 lanes adding to the same word serialise at the memory side
         float v = loss_acc;
 #pragma unroll
