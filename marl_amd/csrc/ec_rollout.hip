@@ -348,11 +348,16 @@ __global__ void __launch_bounds__(256) k_expert_mix(MixArgs a) {
     total = block_sum(total, s_red);
     before = block_sum(before, s_red);
     const int64_t written = *a.written;
+    __shared__ int s_use[MIX_EPB];
+    if (threadIdx.x < MIX_EPB) {  // (the block's own coins in one round trip, not one per iteration of the scan below)
+        const int64_t b = b0 + threadIdx.x;
+        s_use[threadIdx.x] = (b < a.B && a.coin[b] < ratio) ? 1 : 0;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         int64_t rank = before;
         for (int e = 0; e < MIX_EPB; e++) {
-            const int64_t b = b0 + e;
-            const bool use = b < a.B && a.coin[b] < ratio;
+            const bool use = s_use[e] != 0;
             s_slot[e] = (use && rank >= total - a.capacity) ? (written + rank) % a.capacity : (use ? -2 : -1);
             rank += use ? 1 : 0;
         }
