@@ -337,6 +337,10 @@ int ec_ppo_critic_grad(const float* w1, const float* b1, const float* w2, const 
  *       entropy, without Categorical(probs=...)'s [eps, 1-eps] clamp.
  *   critic n_agents = 0: the network reads the raw 9 observation inputs (ValueNet, dgail_network.py:22-34), w1 [64,9].
  * With row_index NULL, flags 0 and avail / mask given they are ec_ppo_actor_grad / ec_ppo_critic_grad. */
+/* Backward passes (grads != NULL) of ec_ppo_*_grad[_ex] and ec_gail_disc_grad sum per-block partial gradients in a fixed
+ * order through a per-device workspace the library allocates at the first such call (13 MB, kept until the process
+ * ends): the same inputs give the same bits.  Passes on one device share the workspace, so they must not overlap
+ * (different streams); MARL_AMD_PPO_ATOMICS=1 in the environment switches to an atomic flush without a workspace. */
 #define EC_PPO_LOGITS 1
 /* flags & EC_PPO_GATHERED: the per-row tables are already in pass order (the caller gathered the minibatch: coalesced
  * reads instead of one random row per lane); row_index then only names each row's agent, (row_index[r]) % n_agents. */

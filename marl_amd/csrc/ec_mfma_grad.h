@@ -134,8 +134,10 @@ __device__ __forceinline__ void block_sum_scalars(float (&v)[NS], float* __restr
 }
 
 // flush an accumulator tile pair into a row-major [n_out][ld] gradient with atomics
+// (atomic = false: plain stores into a block-private copy of the gradient, summed by a second launch)
 template <int TO, int TI>
-__device__ __forceinline__ void flush(float* __restrict__ g, int ld, int n_out, int n_in, const f32x16 (&acc)[TO][TI], int lane) {
+__device__ __forceinline__ void flush(float* __restrict__ g, int ld, int n_out, int n_in, const f32x16 (&acc)[TO][TI], int lane,
+                                      bool atomic = true) {
     const int j = lane & 31, half = lane >> 5;
 #pragma unroll
     for (int to = 0; to < TO; to++)
@@ -144,7 +146,10 @@ __device__ __forceinline__ void flush(float* __restrict__ g, int ld, int n_out, 
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int out = 32 * to + 8 * (r >> 2) + 4 * half + (r & 3), in = 32 * ti + j;
-                if (out < n_out && in < n_in) atomicAdd(g + (size_t)out * ld + in, acc[to][ti][r]);
+                if (out < n_out && in < n_in) {
+                    if (atomic) atomicAdd(g + (size_t)out * ld + in, acc[to][ti][r]);
+                    else g[(size_t)out * ld + in] = acc[to][ti][r];
+                }
             }
 }
 

@@ -19,6 +19,7 @@
 //                gradients ride along as a per-lane running sum of the A operand.  One atomic add per accumulator
 //                register at the end of the wave's row loop.
 #include <cstdlib>
+#include <mutex>
 
 #include "ec_mfma_grad.h"
 
@@ -62,6 +63,10 @@ struct PpoArgs {
     // -log(1 - p + 1e-8)); out_a receives p = sigmoid(z)
     const int64_t* onehot;
     int bce;
+    // backward passes: block b writes its sums to ws[b * ws_stride + i] (i: index into grads; loss at n_params) and
+    // k_ppo_sum adds them to grads / loss in block order -- no atomics, the same bits every time.  NULL: atomics.
+    float* ws;
+    int ws_stride;
 };
 
 // HEAD 0: actor (TO3 output tiles), HEAD 1: critic.  IN1T: tiles of the first layer's dense input (9 + n_agents).
@@ -455,40 +460,55 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
         loss_acc = sc[7];
         if (wave > 0) return;
     }
-    if (p.loss) {  // one atomic per wave: 32 lanes adding to the same word serialise at the memory side
+    const bool to_ws = backward && p.ws != nullptr;
+    const int n3 = HEAD == 0 ? A : 1;
+    const int n_params = H * in1 + H + H * H + H + n3 * H + n3;
+    if (p.loss || to_ws) {  // (atomics: one per wave -- 32 lanes adding to the same word serialise at the memory side)
         float v = loss_acc;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0 && v != 0.0f) atomicAdd(p.loss, v);
+        if (lane == 0) {
+            if (to_ws) p.ws[(size_t)blockIdx.x * p.ws_stride + n_params] = v;
+            else if (v != 0.0f) atomicAdd(p.loss, v);
+        }
     }
 #ifdef ABL_PPO_NOFLUSH  // diagnostic build (make abl_ppo): what the gradient flush costs
     if (backward && p.R < 0) {
 #else
     if (backward) {
 #endif
-        float* g = p.grads;
+        const bool atomic = !to_ws;
+        float* g = to_ws ? p.ws + (size_t)blockIdx.x * p.ws_stride : p.grads;
         float* gW1p = g;
         float* gb1p = gW1p + (size_t)H * in1;
         float* gW2p = gb1p + H;
         float* gb2p = gW2p + H * H;
         float* gW3p = gb2p + H;
-        const int n3 = HEAD == 0 ? A : 1;
         float* gb3p = gW3p + (size_t)n3 * H;
-        flush<2, IN1T>(gW1p, in1, H, in1, gW1, lane);
-        flush<2, 2>(gW2p, H, H, H, gW2, lane);
+        const auto put = [&](float* dst, float v) {
+            if (atomic) atomicAdd(dst, v);
+            else *dst = v;
+        };
+        flush<2, IN1T>(gW1p, in1, H, in1, gW1, lane, atomic);
+        flush<2, 2>(gW2p, H, H, H, gW2, lane, atomic);
+        // bias sums: the two halves of the wave hold the two row parities of the same entries
 #pragma unroll
         for (int to = 0; to < 2; to++) {
-            atomicAdd(gb1p + 32 * to + (lane & 31), gb1[to]);
-            atomicAdd(gb2p + 32 * to + (lane & 31), gb2[to]);
+            const float v1 = gb1[to] + __shfl_xor(gb1[to], 32), v2 = gb2[to] + __shfl_xor(gb2[to], 32);
+            if (half == 0) {
+                put(gb1p + 32 * to + jrow, v1);
+                put(gb2p + 32 * to + jrow, v2);
+            }
         }
         if (HEAD == 0) {
-            flush<T3, 2>(gW3p, H, A, H, gW3, lane);
+            flush<T3, 2>(gW3p, H, A, H, gW3, lane, atomic);
 #pragma unroll
-            for (int to = 0; to < T3; to++)
-                if (32 * to + (lane & 31) < A) atomicAdd(gb3p + 32 * to + (lane & 31), gb3[to]);
+            for (int to = 0; to < T3; to++) {
+                const float v3 = gb3[to] + __shfl_xor(gb3[to], 32);
+                if (half == 0 && 32 * to + jrow < A) put(gb3p + 32 * to + jrow, v3);
+            }
         } else {
             // the 32 lanes of a half hold partial sums of the SAME 32 entries of dW3: reduce them in the wave first
-            // (one atomic per entry per wave instead of 32 colliding on two cache lines)
 #pragma unroll
             for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -496,14 +516,58 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
                     float v = gW3[0][t][r];
 #pragma unroll
                     for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-                    if ((lane & 31) == 0) atomicAdd(gW3p + 32 * t + 8 * (r >> 2) + 4 * half + (r & 3), v);
+                    if (jrow == 0) put(gW3p + 32 * t + 8 * (r >> 2) + 4 * half + (r & 3), v);
                 }
             float vb = gb3c;
 #pragma unroll
             for (int o = 16; o >= 1; o >>= 1) vb += __shfl_xor(vb, o);
-            if (lane == 0) atomicAdd(gb3p, vb);
+            if (lane == 0) put(gb3p, vb);
         }
     }
+}
+
+// second launch of a backward pass: grads[i] += sum over blocks of their private sums, in a fixed order (8 segments of
+// the block range per entry, then the segments in order); loss likewise
+__global__ void __launch_bounds__(256) k_ppo_sum(const float* __restrict__ ws, int ws_stride, int n_blocks, int n_params,
+                                                 float* __restrict__ grads, float* __restrict__ loss) {
+    __shared__ float s_part[8][32];
+    const int pi = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + pi;
+    const int per = (n_blocks + 7) / 8, b0 = seg * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+    float s = 0.0f;
+    if (i <= n_params) {
+#pragma unroll 8
+        for (int b = b0; b < b1; b++) s += ws[(size_t)b * ws_stride + i];
+    }
+    s_part[seg][pi] = s;
+    __syncthreads();
+    if (seg == 0 && i <= n_params) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) t += s_part[q][pi];
+        if (i < n_params) grads[i] += t;
+        else if (loss) loss[0] += t;
+    }
+}
+
+constexpr int PPO_WS_STRIDE = 12800;  // >= the largest parameter count (64 x 64 first layer, 64 actions) + 1
+constexpr int PPO_WS_BLOCKS = 256;
+std::mutex g_ws_mu;
+float* g_ws[64] = {nullptr};
+
+// the per-device workspace of the backward passes (allocated at the first one; calls on one device share it, so passes
+// that overlap on one GPU from different streams must not: MARL_AMD_PPO_ATOMICS=1 restores the atomic flush)
+int ppo_workspace(float** out) {
+    static const bool atomics = getenv("MARL_AMD_PPO_ATOMICS") && atoi(getenv("MARL_AMD_PPO_ATOMICS")) != 0;
+    *out = nullptr;
+    if (atomics) return EC_OK;
+    int dev = 0;
+    EC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return EC_OK;
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    if (!g_ws[dev]) EC_HIP(hipMalloc(reinterpret_cast<void**>(&g_ws[dev]), sizeof(float) * PPO_WS_STRIDE * PPO_WS_BLOCKS));
+    *out = g_ws[dev];
+    return EC_OK;
 }
 
 constexpr size_t PPO_LDS_MAX = 160 * 1024;
@@ -538,7 +602,16 @@ int launch_ppo(const PpoArgs& a, hipStream_t stream) {
         static const int min_tiles = getenv("MARL_AMD_PPO_MIN_TILES") ? atoi(getenv("MARL_AMD_PPO_MIN_TILES")) : 1;
         const int64_t want = (tiles + (int64_t)nw * min_tiles - 1) / ((int64_t)nw * min_tiles);
         if (blocks > want) blocks = want < 1 ? 1 : want;
-        hipLaunchKernelGGL((k_ppo<HEAD, TO3, IN1T, true>), dim3((unsigned)blocks), dim3(64 * nw), lds, stream, a);
+        PpoArgs b = a;
+        const int n3 = HEAD == 0 ? a.A : 1;
+        const int n_params = H * (OBS + a.n_agents) + H + H * H + H + n3 * H + n3;
+        if (int rc = ppo_workspace(&b.ws)) return rc;
+        b.ws_stride = PPO_WS_STRIDE;
+        if (n_params + 1 > PPO_WS_STRIDE || blocks > PPO_WS_BLOCKS) b.ws = nullptr;
+        hipLaunchKernelGGL((k_ppo<HEAD, TO3, IN1T, true>), dim3((unsigned)blocks), dim3(64 * nw), lds, stream, b);
+        if (b.ws)
+            hipLaunchKernelGGL(k_ppo_sum, dim3((n_params + 1 + 31) / 32), dim3(256), 0, stream, b.ws, b.ws_stride, (int)blocks,
+                               n_params, a.grads, a.loss);
     } else {
         EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ppo<HEAD, TO3, IN1T, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -576,7 +649,7 @@ int ec_ppo_actor_grad_ex(const float* w1, const float* b1, const float* w2, cons
     if (old_logp && !adv) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: old_logp without adv");
     if (grads && !old_logp && !(flags & EC_PPO_NLL)) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: grads without old_logp");
     PpoArgs a{w1, b1, w2, b2, w3, b3, obs, avail, actions, old_logp, adv, nullptr, mask, rows, n_agents, n_actions,
-              eps_clip, entropy_coef, inv_denom, grads, loss, logp, entropy, row_index, flags, nullptr, 0};
+              eps_clip, entropy_coef, inv_denom, grads, loss, logp, entropy, row_index, flags, nullptr, 0, nullptr, 0};
     const int TO3 = n_actions <= 32 ? 1 : 2, IN1T = OBS + n_agents <= 32 ? 1 : 2;
     if (TO3 == 1 && IN1T == 1) return launch_ppo<0, 1, 1>(a, (hipStream_t)stream);
     if (TO3 == 1) return launch_ppo<0, 1, 2>(a, (hipStream_t)stream);
@@ -603,7 +676,7 @@ int ec_ppo_critic_grad_ex(const float* w1, const float* b1, const float* w2, con
     if (int rc = check_common("ec_ppo_critic_grad", need, 7, rows, hidden, n_agents)) return rc;
     if (grads && !target) return ec::fail(EC_EINVAL, "ec_ppo_critic_grad: grads without target");
     PpoArgs a{w1, b1, w2, b2, w3, b3, obs, nullptr, nullptr, nullptr, nullptr, target, mask, rows, n_agents, 1,
-              0.0f, 0.0f, inv_denom, grads, loss, values, nullptr, row_index, 0, nullptr, 0};
+              0.0f, 0.0f, inv_denom, grads, loss, values, nullptr, row_index, 0, nullptr, 0, nullptr, 0};
     if (OBS + n_agents <= 32) return launch_ppo<1, 1, 1>(a, (hipStream_t)stream);
     return launch_ppo<1, 1, 2>(a, (hipStream_t)stream);
 }
@@ -617,7 +690,7 @@ int ec_gail_disc_grad(const float* w1, const float* b1, const float* w2, const f
     if (n_actions < 1) return ec::fail(EC_EINVAL, "ec_gail_disc_grad: n_actions %d", n_actions);
     // the critic instantiation with the action as the one-hot column and the BCE head
     PpoArgs a{w1, b1, w2, b2, w3, b3, obs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rows, n_actions, 1,
-              0.0f, 0.0f, inv_denom, grads, loss, prob, nullptr, nullptr, 0, actions, expert ? 1 : -1};
+              0.0f, 0.0f, inv_denom, grads, loss, prob, nullptr, nullptr, 0, actions, expert ? 1 : -1, nullptr, 0};
     if (OBS + n_actions <= 32) return launch_ppo<1, 1, 1>(a, (hipStream_t)stream);
     return launch_ppo<1, 1, 2>(a, (hipStream_t)stream);
 }

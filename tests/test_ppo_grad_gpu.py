@@ -201,3 +201,27 @@ def test_gail_disc_loss_and_gradients(N, rows):
         g, wv = fg.flat[off:off + k].double().cpu(), want[off:off + k]
         assert float((g - wv).abs().max()) <= 1e-4 * float(wv.abs().max()) + 1e-9, name
         off += k
+
+
+def test_backward_passes_are_bit_reproducible():
+    """The backward passes sum per-block partial gradients in block order (no atomics): two runs on the same inputs give
+    the same bits, for both heads and through the minibatch index."""
+    from marl_amd.utils import ppo_device
+    dev = th.device("cuda")
+    N, rows = 10, 200000
+    actor, critic = _nets(N, 21)
+    actor, critic = actor.to(dev), critic.to(dev)
+    obs, avail, actions, adv, mask, target = (t.to(dev) for t in _batch(N, rows, 5))
+    old_logp = -th.rand(rows, device=dev)
+    idx = th.randperm(rows, device=dev)[:70000].contiguous()
+    outs = []
+    for _ in range(2):
+        fa, fc = ppo_device.FlatGrads(actor), ppo_device.FlatGrads(critic)
+        loss = th.zeros(2, device=dev)
+        ppo_device.actor_pass(actor, obs, avail, actions, mask, N, old_logp=old_logp, adv=adv, eps_clip=0.2, entropy_coef=0.01,
+                              inv_denom=1.0 / rows, grads=fa.flat, loss=loss[0:1], row_index=idx)
+        ppo_device.critic_pass(critic, obs, mask, N, target=target, inv_denom=1.0 / rows, grads=fc.flat, loss=loss[1:2])
+        th.cuda.synchronize()
+        outs.append((fa.flat.clone(), fc.flat.clone(), loss.clone()))
+    for a, b in zip(*outs):
+        assert th.equal(a, b)
