@@ -381,6 +381,25 @@ int ec_expert_mix(const float* coin, const float* ratio, const int64_t* expert_a
                   int64_t* exec_actions, float* ring_obs, int64_t* ring_actions, int64_t* written, int64_t* n_expert,
                   void* stream);
 
+/* The tail of a GAIL-discriminator layer -- BatchNorm1d in training mode, ReLU, Dropout(p) (gail_network.py:97-125:
+ * fc -> bn -> activation -> dropout) -- over x [rows, C] fp32, C a multiple of 4 with C/4 dividing 256, with the batch
+ * statistics folded into scale = invstd * weight and shift = bias - mean * scale by the caller:
+ *   fwd:      out = relu(x * scale + shift) * keep / (1 - p)
+ *   bwd_sums: partials [n_partials][2][C] <- per-block sums over rows of dy and of dy * x,
+ *             dy = dout * keep / (1 - p) * [x * scale + shift > 0]   (the caller adds the partials up)
+ *   bwd_dx:   dx = a * dy + b * x + c   with per-column a, b, c (the training-mode BatchNorm backward, assembled by the
+ *             caller from the sums and the statistics)
+ * keep: `mask` [rows, C] u8 when given, else a counter-based Bernoulli(1 - p) draw from (seed, element index) that the
+ * backward recomputes instead of reading.  Replaces F.batch_norm / relu / F.dropout and their autograd backward. */
+int ec_bn_relu_dropout_fwd(const float* x, const float* scale, const float* shift, const uint8_t* mask, uint64_t seed, float p,
+                           int64_t rows, int32_t C, float* out, void* stream);
+int ec_bn_relu_dropout_bwd_sums(const float* dout, const float* x, const float* scale, const float* shift, const uint8_t* mask,
+                                uint64_t seed, float p, int64_t rows, int32_t C, int32_t n_partials, float* partials,
+                                void* stream);
+int ec_bn_relu_dropout_bwd_dx(const float* dout, const float* x, const float* scale, const float* shift, const uint8_t* mask,
+                              uint64_t seed, float p, const float* a, const float* b, const float* c, int64_t rows, int32_t C,
+                              float* dx, void* stream);
+
 const char* ec_last_error(void);
 const char* ec_version(void);
 

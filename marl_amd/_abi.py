@@ -163,13 +163,17 @@ def lib():
     L.ec_ppo_critic_grad_ex.argtypes = [vp] * 9 + [i64, i32, i32, f32, vp, vp, vp, vp, vp]
     L.ec_gail_disc_grad.argtypes = [vp] * 8 + [i64, i32, i32, i32, f32, vp, vp, vp, vp]
     L.ec_expert_mix.argtypes = [vp] * 5 + [i64, i32, i32, i64] + [vp] * 6
+    u64 = C.c_uint64
+    L.ec_bn_relu_dropout_fwd.argtypes = [vp, vp, vp, vp, u64, f32, i64, i32, vp, vp]
+    L.ec_bn_relu_dropout_bwd_sums.argtypes = [vp, vp, vp, vp, vp, u64, f32, i64, i32, i32, vp, vp]
+    L.ec_bn_relu_dropout_bwd_dx.argtypes = [vp, vp, vp, vp, vp, u64, f32, vp, vp, vp, i64, i32, vp, vp]
     L.ec_store_transition.argtypes = [vp] * 7 + [i64, i32, i32, i32, i64, i64] + [vp] * 8
     L.ec_store_episode.argtypes = [vp] * 9 + [i64, i32, i32, i32, i64] + [vp] * 10
     L.ec_store_episode_static.argtypes = [vp] * 9 + [i64, i32, i32, i32, i64] + [vp] * 8
     for fn in ("ec_create", "ec_destroy", "ec_reset", "ec_observe", "ec_step", "ec_random_policy", "ec_status",
                "ec_debug_dump", "ec_debug_rng_cursors", "ec_debug_live_tasks", "ec_info", "ec_gae",
                "ec_policy_forward", "ec_gail_reward", "ec_diffusion_reward", "ec_diffusion_grad", "ec_expert_policy",
-               "ec_ppo_actor_grad", "ec_ppo_critic_grad", "ec_ppo_actor_grad_ex", "ec_ppo_critic_grad_ex", "ec_gail_disc_grad", "ec_store_transition", "ec_expert_mix", "ec_store_episode", "ec_store_episode_static",
+               "ec_ppo_actor_grad", "ec_ppo_critic_grad", "ec_ppo_actor_grad_ex", "ec_ppo_critic_grad_ex", "ec_gail_disc_grad", "ec_store_transition", "ec_bn_relu_dropout_fwd", "ec_bn_relu_dropout_bwd_sums", "ec_bn_relu_dropout_bwd_dx", "ec_expert_mix", "ec_store_episode", "ec_store_episode_static",
                "ec_step_random_policy", "ec_rollout_random_policy", "ec_rollout_mlp_policy"):
         getattr(L, fn).restype = C.c_int
     L.ec_last_error.restype = C.c_char_p

@@ -1,0 +1,197 @@
+// ec_bn.hip — the tail of a GAIL-discriminator layer, BatchNorm1d (training mode) -> ReLU -> Dropout(p), as streaming
+// kernels over [rows, C] fp32 (rl/policy_gradient_rl/gail/gail_network.py:59-132: fc -> bn -> activation -> dropout,
+// three times, on 4.1 M .. 65.5 M rows per update).
+//
+// torch runs the tail as batch_norm (statistics, transform), relu, dropout (+ mask) forward and threshold_backward,
+// masked_scale, batch_norm_backward (reduce, elementwise) backward: ~16 passes over a [rows, C] tensor per layer, and it
+// keeps four such tensors for the backward.  Here, with the batch statistics given (one var_mean pass by the caller):
+//   forward   out = relu(x * scale + shift) * keep / (1 - p)                          1 read + 1 write
+//   backward  dy  = dout * keep / (1 - p) * [x * scale + shift > 0]
+//             s1 = sum_rows dy,  s2 = sum_rows dy * x        (per-block partials)     2 reads
+//             dx  = a * dy + b * x + c                                                2 reads + 1 write
+// with a, b, c per column from s1, s2 and the statistics (the exact training-mode backward through mean and variance,
+// assembled by the caller).  keep is either an explicit byte mask (tests replay the reference's draws) or a counter-based
+// draw from (seed, element index), recomputed in the backward instead of stored.  HBM-bound by construction.
+#include "ec_common.h"
+
+namespace {
+
+__device__ __forceinline__ bool keep_draw(uint64_t seed, uint64_t idx, uint32_t thr24) {
+    uint64_t z = seed + idx * 0x9e3779b97f4a7c15ull;  // splitmix64 finaliser of a Weyl sequence
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 40) >= thr24;  // uniform 24-bit draw >= p * 2^24  <=>  keep with probability 1 - p
+}
+
+struct BnArgs {
+    const float* x;      // [rows, C]
+    const float* dout;   // [rows, C] (backward)
+    const float* scale;  // [C] invstd * weight
+    const float* shift;  // [C] bias - mean * scale
+    const uint8_t* mask; // [rows, C] keep flags, or NULL: keep_draw(seed, row * C + col)
+    uint64_t seed;
+    uint32_t thr24;
+    float inv_keep;      // 1 / (1 - p)
+    int64_t rows;
+    int C;               // a multiple of 4, <= 256
+    const float *a, *b, *c;  // [C] (dx)
+    float* out;          // forward: out;  dx: dx;  sums: partials [blocks][2][C]
+};
+
+__device__ __forceinline__ void keep4(const BnArgs& p, int64_t e, bool (&k)[4]) {
+    if (p.mask) {
+        const uchar4 m = *reinterpret_cast<const uchar4*>(p.mask + e);
+        k[0] = m.x != 0;
+        k[1] = m.y != 0;
+        k[2] = m.z != 0;
+        k[3] = m.w != 0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) k[j] = keep_draw(p.seed, (uint64_t)(e + j), p.thr24);
+    }
+}
+
+// MODE 0: forward;  MODE 1: dx
+template <int MODE>
+__global__ void __launch_bounds__(256) k_bn_tail(BnArgs p) {
+    const int q4 = p.C >> 2;
+    const int64_t n4 = p.rows * q4;
+    // C/4 divides the block size and the grid stride: a thread stays on one column quad
+    const int col = (int)(threadIdx.x % q4) * 4;
+    const float4 sc = *reinterpret_cast<const float4*>(p.scale + col), sh = *reinterpret_cast<const float4*>(p.shift + col);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i * 4;
+        const float4 x = *reinterpret_cast<const float4*>(p.x + e);
+        bool k[4];
+        keep4(p, e, k);
+        const float xv[4] = {x.x, x.y, x.z, x.w}, scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+        float o[4];
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float y = xv[j] * scv[j] + shv[j];
+                o[j] = (k[j] && y > 0.0f) ? y * p.inv_keep : 0.0f;
+            }
+        } else {
+            const float4 d = *reinterpret_cast<const float4*>(p.dout + e);
+            const float4 a = *reinterpret_cast<const float4*>(p.a + col), b = *reinterpret_cast<const float4*>(p.b + col),
+                         c = *reinterpret_cast<const float4*>(p.c + col);
+            const float dv[4] = {d.x, d.y, d.z, d.w}, av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w},
+                        cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float y = xv[j] * scv[j] + shv[j];
+                const float dy = (k[j] && y > 0.0f) ? dv[j] * p.inv_keep : 0.0f;
+                o[j] = av[j] * dy + bv[j] * xv[j] + cv[j];
+            }
+        }
+        *reinterpret_cast<float4*>(p.out + e) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// partials[blk][0][col] = sum over the block's rows of dy, [blk][1][col] of dy * x.  A thread owns one column quad and
+// every (256 / (C/4))-th row of the block's range; the row lanes are summed through LDS in a fixed order.
+__global__ void __launch_bounds__(256) k_bn_tail_sums(BnArgs p) {
+    __shared__ float s_red[2][4][256];
+    const int q4 = p.C >> 2;
+    const int lanes = 256 / q4;                       // row lanes per block (C <= 256 and a power of two times 4)
+    const int q = threadIdx.x % q4, rl = threadIdx.x / q4;
+    const int col = q * 4;
+    const int64_t per = (p.rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < p.rows ? r0 + per : p.rows;
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (rl < lanes) {
+        const float4 sc = *reinterpret_cast<const float4*>(p.scale + col), sh = *reinterpret_cast<const float4*>(p.shift + col);
+        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+        for (int64_t r = r0 + rl; r < r1; r += lanes) {
+            const int64_t e = r * p.C + col;
+            const float4 x = *reinterpret_cast<const float4*>(p.x + e), d = *reinterpret_cast<const float4*>(p.dout + e);
+            bool k[4];
+            keep4(p, e, k);
+            const float xv[4] = {x.x, x.y, x.z, x.w}, dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float y = xv[j] * scv[j] + shv[j];
+                const float dy = (k[j] && y > 0.0f) ? dv[j] * p.inv_keep : 0.0f;
+                s1[j] += dy;
+                s2[j] += dy * xv[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        s_red[0][j][threadIdx.x] = s1[j];
+        s_red[1][j][threadIdx.x] = s2[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < q4) {
+#pragma unroll
+        for (int w = 0; w < 2; w++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float t = 0.0f;
+                for (int l = 0; l < lanes; l++) t += s_red[w][j][l * q4 + q];
+                p.out[((size_t)blockIdx.x * 2 + w) * p.C + col + j] = t;
+            }
+    }
+}
+
+int bn_check(const char* what, const BnArgs& a, float p) {
+    if (!a.x || !a.scale || !a.shift || !a.out) return ec::fail(EC_EINVAL, "%s: null pointer", what);
+    if (a.rows < 0 || a.C < 4 || a.C > 256 || (a.C & 3) || (256 % (a.C >> 2)))
+        return ec::fail(EC_EINVAL, "%s: rows %lld, C %d (C must be 4..256 with C/4 dividing 256)", what, (long long)a.rows, a.C);
+    if (!(p >= 0.0f && p < 1.0f)) return ec::fail(EC_EINVAL, "%s: dropout p = %g outside [0, 1)", what, p);
+    return EC_OK;
+}
+
+int bn_grid(int64_t n4) {
+    const int64_t b = (n4 + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+BnArgs bn_args(const float* x, const float* dout, const float* scale, const float* shift, const uint8_t* mask, uint64_t seed,
+               float p, int64_t rows, int C, const float* a, const float* b, const float* c, float* out) {
+    BnArgs r{x, dout, scale, shift, mask, seed, (uint32_t)((double)p * 16777216.0), 1.0f / (1.0f - p), rows, C, a, b, c, out};
+    return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ec_bn_relu_dropout_fwd(const float* x, const float* scale, const float* shift, const uint8_t* mask, uint64_t seed, float p,
+                           int64_t rows, int32_t C, float* out, void* stream) {
+    if (rows == 0) return EC_OK;
+    const BnArgs a = bn_args(x, nullptr, scale, shift, mask, seed, p, rows, C, nullptr, nullptr, nullptr, out);
+    if (int rc = bn_check("ec_bn_relu_dropout_fwd", a, p)) return rc;
+    hipLaunchKernelGGL(k_bn_tail<0>, dim3(bn_grid(rows * (C >> 2))), dim3(256), 0, (hipStream_t)stream, a);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+int ec_bn_relu_dropout_bwd_sums(const float* dout, const float* x, const float* scale, const float* shift, const uint8_t* mask,
+                                uint64_t seed, float p, int64_t rows, int32_t C, int32_t n_partials, float* partials,
+                                void* stream) {
+    if (rows == 0) return EC_OK;
+    const BnArgs a = bn_args(x, dout, scale, shift, mask, seed, p, rows, C, nullptr, nullptr, nullptr, partials);
+    if (int rc = bn_check("ec_bn_relu_dropout_bwd_sums", a, p)) return rc;
+    if (!dout || n_partials < 1) return ec::fail(EC_EINVAL, "ec_bn_relu_dropout_bwd_sums: null dout or n_partials < 1");
+    hipLaunchKernelGGL(k_bn_tail_sums, dim3(n_partials), dim3(256), 0, (hipStream_t)stream, a);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+int ec_bn_relu_dropout_bwd_dx(const float* dout, const float* x, const float* scale, const float* shift, const uint8_t* mask,
+                              uint64_t seed, float p, const float* a_, const float* b_, const float* c_, int64_t rows, int32_t C,
+                              float* dx, void* stream) {
+    if (rows == 0) return EC_OK;
+    const BnArgs a = bn_args(x, dout, scale, shift, mask, seed, p, rows, C, a_, b_, c_, dx);
+    if (int rc = bn_check("ec_bn_relu_dropout_bwd_dx", a, p)) return rc;
+    if (!dout || !a_ || !b_ || !c_) return ec::fail(EC_EINVAL, "ec_bn_relu_dropout_bwd_dx: null pointer");
+    hipLaunchKernelGGL(k_bn_tail<1>, dim3(bn_grid(rows * (C >> 2))), dim3(256), 0, (hipStream_t)stream, a);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+}  // extern "C"

@@ -133,6 +133,77 @@ class _TallBnReluDropFn(th.autograd.Function):
         return dx, s2, s1, None, None
 
 
+def _explicit_mask(x, p):
+    """Hook of the HIP layer tail: None = the kernels draw the keep mask themselves (counter-based, from a seed); the
+    reference-replay tests return the reference's recorded mask here."""
+    return None
+
+
+class _BnReluDropHipFn(th.autograd.Function):
+    """The same node on the HIP kernels of csrc/ec_bn.hip (fp32 on the device): forward 1 read + 1 write after the
+    statistics pass, backward 4 reads + 1 write, only x (and an explicit mask, if one was given) kept."""
+
+    N_PARTIALS = 1024
+
+    @staticmethod
+    def _args(x, scale, shift, mask, seed, p):
+        import ctypes as C
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        return vp, (vp(x), vp(scale), vp(shift), vp(mask), C.c_uint64(seed), C.c_float(p))
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, p):
+        import ctypes as C
+
+        from marl_amd import _abi
+        x = x.contiguous()
+        var, mean = th.var_mean(x, dim=0, unbiased=False)
+        invstd = th.rsqrt(var + eps)
+        scale = (invstd * weight).contiguous()
+        shift = (bias - mean * scale).contiguous()
+        mask = _explicit_mask(x, p)
+        if mask is not None:
+            mask = mask.to(device=x.device, dtype=th.uint8).contiguous()
+        seed = int(th.empty((), dtype=th.int64).random_())   # torch's CPU generator: follows th.manual_seed, no device sync
+        out = th.empty_like(x)
+        rows, Cc = x.shape
+        stream = C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)
+        vp, head = _BnReluDropHipFn._args(x, scale, shift, mask, seed, p)
+        with th.cuda.device(x.device):
+            _abi.check(_abi.lib().ec_bn_relu_dropout_fwd(*head, rows, Cc, vp(out), stream), "ec_bn_relu_dropout_fwd")
+        ctx.save_for_backward(x, weight, mean, invstd, scale, shift, mask)
+        ctx.seed, ctx.p = seed, p
+        ctx.mark_non_differentiable(mean, var)
+        return out, mean, var
+
+    @staticmethod
+    def backward(ctx, dout, _dmean, _dvar):
+        import ctypes as C
+
+        from marl_amd import _abi
+        x, weight, mean, invstd, scale, shift, mask = ctx.saved_tensors
+        dout = dout.contiguous()
+        rows, Cc = x.shape
+        n_part = int(min(_BnReluDropHipFn.N_PARTIALS, max(1, rows // 64)))
+        partials = th.empty(n_part, 2, Cc, dtype=th.float32, device=x.device)
+        stream = C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)
+        vp, head = _BnReluDropHipFn._args(x, scale, shift, mask, ctx.seed, ctx.p)
+        with th.cuda.device(x.device):
+            _abi.check(_abi.lib().ec_bn_relu_dropout_bwd_sums(vp(dout), *head, rows, Cc, n_part, vp(partials), stream),
+                       "ec_bn_relu_dropout_bwd_sums")
+            s = partials.sum(0)
+            s1 = s[0]
+            s2 = (s[1] - mean * s1) * invstd             # sum dy * xhat
+            a = weight * invstd
+            b = -a * invstd * s2 / rows
+            c = -a * s1 / rows - b * mean
+            a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
+            dx = th.empty_like(x)
+            _abi.check(_abi.lib().ec_bn_relu_dropout_bwd_dx(vp(dout), *head, vp(a), vp(b), vp(c), rows, Cc, vp(dx), stream),
+                       "ec_bn_relu_dropout_bwd_dx")
+        return dx, s2, s1, None, None
+
+
 class TallBatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d (same parameters, buffers and state_dict keys); training-mode inputs of TALL_NUMEL elements or
     more take _TallBatchNormFn."""
@@ -146,9 +217,15 @@ class TallBatchNorm1d(nn.BatchNorm1d):
         self._track(x.shape[0], mean, var)
         return y
 
+    def hip_ok(self, x):
+        C = x.shape[-1]
+        return (self.training and x.dim() == 2 and x.is_cuda and x.dtype == th.float32 and x.shape[0] > 1
+                and C % 4 == 0 and C <= 256 and 256 % (C // 4) == 0 and self.weight is not None)
+
     def relu_dropout(self, x, p):
-        """dropout(relu(self(x)), p) for a tall training-mode input, as one autograd node"""
-        y, mean, var = _TallBnReluDropFn.apply(x, self.weight, self.bias, self.eps, float(p))
+        """dropout(relu(self(x)), p) for a training-mode input, as one autograd node (HIP kernels on the device)"""
+        fn = _BnReluDropHipFn if self.hip_ok(x) else _TallBnReluDropFn
+        y, mean, var = fn.apply(x, self.weight, self.bias, self.eps, float(p))
         self._track(x.shape[0], mean, var)
         return y
 
@@ -192,7 +269,7 @@ class Discriminator(nn.Module):
         for i in (1, 2, 3):
             x = getattr(self, "fc%d" % i)(x)
             bn, drop = getattr(self, "bn%d" % i), getattr(self, "dropout%d" % i)
-            if bn.tall(x) and drop.training and self.activate_func is F.relu:
+            if (bn.hip_ok(x) or bn.tall(x)) and drop.training and 0.0 <= drop.p < 1.0 and self.activate_func is F.relu:
                 x = bn.relu_dropout(x, drop.p)      # one autograd node for the layer's tail (memory at 10^7..10^8 rows)
                 continue
             if x.shape[0] > 1:

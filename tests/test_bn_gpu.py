@@ -1,0 +1,80 @@
+"""The HIP tail of a GAIL-discriminator layer (csrc/ec_bn.hip: BatchNorm1d in training mode -> ReLU -> Dropout as one
+autograd node) against torch's own modules (gail_network.py:97-125 of the reference runs fc -> bn -> activation ->
+dropout).  Tolerance: fp32 streaming arithmetic against a float64 reference, 1e-5 relative on outputs, 1e-4 of a
+gradient tensor's largest entry."""
+import pytest
+import torch as th
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows,C,p", [(2, 32, 0.2), (640, 128, 0.3), (100003, 64, 0.3), (4097, 128, 0.0)])
+def test_hip_layer_tail_matches_modules(rows, C, p, monkeypatch):
+    import marl_amd.rl.policy_gradient_rl.gail.gail_network as gn
+    dev = th.device("cuda")
+    th.manual_seed(rows + C)
+    x = th.randn(rows, C) * th.linspace(0.5, 2.0, C) + th.linspace(-1, 1, C)
+    g = th.randn(rows, C)
+    mask = th.rand(rows, C) >= p
+    stock = th.nn.BatchNorm1d(C).double()
+    tall = gn.TallBatchNorm1d(C)
+    with th.no_grad():
+        for m in (stock, tall):
+            m.weight.copy_(th.linspace(0.5, 1.5, C))
+            m.bias.copy_(th.linspace(-0.5, 0.5, C))
+        # elements whose pre-activation is within fp32 rounding of the ReLU kink have no well-defined gradient to
+        # compare (one in ~10^7 at these sizes): drop them through the mask
+        y = th.nn.functional.batch_norm(x.double(), None, None, stock.weight, stock.bias, True, 0.0, stock.eps)
+        mask &= y.abs() > 1e-4
+    monkeypatch.setattr(gn, "_explicit_mask", lambda x_, p_: mask.to(x_.device))
+    tall = tall.to(dev)
+    xa = x.double().requires_grad_(True)
+    out_a = th.relu(stock(xa)) * mask / (1 - p)
+    (out_a * g.double()).sum().backward()
+    xb = x.to(dev).requires_grad_(True)
+    assert tall.hip_ok(xb)
+    out_b = tall.relu_dropout(xb, p)
+    (out_b * g.to(dev)).sum().backward()
+    th.cuda.synchronize()
+    assert th.allclose(out_b.detach().cpu().double(), out_a.detach(), rtol=1e-5, atol=1e-5)
+    for name, a, b in (("dx", xa.grad, xb.grad), ("dweight", stock.weight.grad, tall.weight.grad),
+                       ("dbias", stock.bias.grad, tall.bias.grad)):
+        err = float((b.detach().cpu().double() - a).abs().max())
+        # (two rows: the BatchNorm backward cancels to almost nothing, what is left is fp32 rounding of O(|dout| * scale) terms)
+        assert err <= 1e-4 * float(a.abs().max()) + (1e-4 if rows < 64 else 1e-7), (name, err)
+    assert th.allclose(tall.running_mean.cpu().double(), stock.running_mean, rtol=1e-5, atol=1e-6)
+    assert th.allclose(tall.running_var.cpu().double(), stock.running_var, rtol=1e-5, atol=1e-6)
+
+
+def test_hip_layer_tail_own_mask():
+    """Without an explicit mask the kernels draw it from (seed, element index): about 1 - p of the elements are kept,
+    the backward recomputes the same mask (its input gradient equals torch's for the mask read off the forward output),
+    two seeds differ, and the same torch seed reproduces the same mask."""
+    import marl_amd.rl.policy_gradient_rl.gail.gail_network as gn
+    dev = th.device("cuda")
+    rows, C, p = 200000, 128, 0.3
+    bn = gn.TallBatchNorm1d(C).to(dev)
+    ref = th.nn.BatchNorm1d(C).to(dev)
+    with th.no_grad():
+        bn.bias.fill_(5.0)    # pre-activations = xhat + 5: positive, so that out > 0 reads off the keep mask
+        ref.bias.fill_(5.0)
+    x = th.randn(rows, C, device=dev)
+    g = th.randn(rows, C, device=dev)
+    xb = x.clone().requires_grad_(True)
+    th.manual_seed(11)
+    out = bn.relu_dropout(xb, p)
+    (out * g).sum().backward()
+    kept = out > 0
+    frac = float(kept.float().mean())
+    assert abs(frac - (1 - p)) < 2e-3, frac
+    xa = x.clone().requires_grad_(True)
+    (th.relu(ref(xa)) * kept / (1 - p) * g).sum().backward()
+    assert float((xa.grad - xb.grad).abs().max()) < 1e-4 * float(xa.grad.abs().max())
+    th.manual_seed(11)
+    again = bn.relu_dropout(x, p)
+    th.manual_seed(12)
+    other = bn.relu_dropout(x, p)
+    assert th.equal(again > 0, kept) and not th.equal(other > 0, kept)
+    cols, rws = kept.float().mean(0), kept.float().mean(1)          # no column or row pattern
+    assert float(cols.min()) > 0.69 and float(cols.max()) < 0.71
+    assert float(rws.min()) > 0.45 and float(rws.max()) < 0.92

@@ -144,11 +144,23 @@ class _DropoutReplay:
             return x * m.to(x.dtype) / (1.0 - p)
 
         F.dropout = dropout
+        # the HIP layer tail (BatchNorm -> ReLU -> Dropout in one node, csrc/ec_bn.hip) takes its keep mask from this hook
+        import marl_amd.rl.policy_gradient_rl.gail.gail_network as gn
+        self._orig_hook = gn._explicit_mask
+
+        def explicit(x, p):
+            m = self.masks[self.pos]
+            self.pos += 1
+            assert m.shape == x.shape, (m.shape, x.shape)
+            return m
+        gn._explicit_mask = explicit
         return self
 
     def __exit__(self, *exc):
         import torch.nn.functional as F
+        import marl_amd.rl.policy_gradient_rl.gail.gail_network as gn
         F.dropout = self._orig
+        gn._explicit_mask = self._orig_hook
 
 
 @pytest.mark.parametrize("device", DEVICES)
