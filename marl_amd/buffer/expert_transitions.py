@@ -72,10 +72,10 @@ class ExpertTransitions:
                        "ec_expert_mix")
         return out
 
-    def sample_transitions(self, n):
+    def sample_transitions(self, n, size=None):
         """n distinct transitions, uniformly (np.random.choice(len, n, replace=False) of the reference):
-        returns obs [n,N,O], actions [n,N]."""
-        size = len(self)
+        returns obs [n,N,O], actions [n,N].  `size`: len(self) when the caller already has it (len() synchronises)."""
+        size = len(self) if size is None else int(size)
         n = min(int(n), size)
         idx = self.rng.choice_without_replacement(size, n)
         return self.obs[idx], self.actions[idx]

@@ -170,6 +170,7 @@ class GAILAgent:
         inv_denom = 1.0 / float(all_reduce_sum_(masks.sum().reshape(1).clone()))
         self.update_bc_weight()
         losses = th.zeros(2, device=self.device)
+        n_expert = len(self.expert_transitions)
         for _ in range(a.epochs):
             losses.zero_()
             self._fg_critic.zero_()
@@ -184,9 +185,12 @@ class GAILAgent:
             ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, old_logp=old_logp, adv=advantages,
                                   eps_clip=a.eps_clip, entropy_coef=a.entropy_coef if a.use_entropy else 0.0,
                                   inv_denom=inv_denom, grads=self._fg_actor.flat, loss=losses[1:2])
-            bc_loss = self.compute_bc_loss()
-            if bc_loss.requires_grad:  # (a constant zero while no expert transition is stored, :86-87)
-                (self.bc_loss_weight * bc_loss / world_size()).backward()
+            if n_expert > 0:  # (the BC term is a constant zero while no expert transition is stored, :86-87)
+                # gail_agent.py:85-107: NLL of the expert's actions on 64 sampled transitions (unmasked logits), on the
+                # same kernel with the cross-entropy objective; adds into the actor's flat gradient
+                e_obs, e_act = self.expert_transitions.sample_transitions(64, size=n_expert)
+                ppo_device.actor_pass(self.actor, e_obs, None, e_act, None, N, grads=self._fg_actor.flat, logits=True,
+                                      nll=True, inv_denom=self.bc_loss_weight / (e_act.numel() * world_size()))
             all_reduce_sum_(self._fg_actor.flat)
             if a.use_grad_clip:
                 th.nn.utils.clip_grad_norm_(self.actor.parameters(), a.grad_norm_clip)
