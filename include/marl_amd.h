@@ -164,6 +164,21 @@ int ec_rollout_mlp_policy(ec_handle h, int32_t n_steps, const float* w1, const f
                           const int32_t* avail0, int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
                           float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail, void* stream);
 
+/* ec_rollout_mlp_policy for the expert-guided rollouts of GAILRunner / DGAILRunner (runners/gail_runner.py:72-98,
+ * runners/dgail_runner.py:46-94): at step t env b executes the expert's decision (ec_expert_policy's, evaluated inside the
+ * launch on the state step t-1 left) iff coin[t][b] < ratios[t], else the Actor's draw.
+ *   coin [n_steps,B] f32 uniform draws, ratios [n_steps] f32 (device);
+ *   actions [n_steps,B,N] <- the AGENT's draw of every step (what the runners file into the PPO buffer, :73-77 / :81),
+ *   expert_actions [n_steps,B,N] <- the expert's decision of every step (ec_expert_append_episode files the expert-driven
+ *   ones); everything else as ec_rollout_mlp_policy.  Equals n_steps rounds of ec_policy_forward, ec_expert_policy,
+ *   select, ec_step bit for bit (tests/test_rollout_gpu.py). */
+int ec_rollout_mlp_expert_policy(ec_handle h, int32_t n_steps, const float* w1, const float* b1, const float* w2,
+                                 const float* b2, const float* w3, const float* b3, const float* uniforms, const float* obs0,
+                                 const int32_t* avail0, const float* coin, const float* ratios, int64_t* actions,
+                                 int64_t* expert_actions, float* reward, uint8_t* terminated, int32_t* counters,
+                                 float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail,
+                                 void* stream);
+
 /* The expert of the GAIL / DGAIL runners for every env of the handle: OptimalAgent.get_current_optimal_action
  * (optimal/optimal_agent.py:102-120) = _conservative_action_selection at conservativeness 1.0 (:166-209) with the
  * reliability / time-margin / load / efficiency scores of :211-375, evaluated on the device state instead of walking
@@ -380,6 +395,18 @@ int ec_expert_mix(const float* coin, const float* ratio, const int64_t* expert_a
                   const float* obs, int64_t n_envs, int32_t n_agents, int32_t obs_dim, int64_t capacity,
                   int64_t* exec_actions, float* ring_obs, int64_t* ring_actions, int64_t* written, int64_t* n_expert,
                   void* stream);
+
+/* The FIFO append of ec_expert_mix for a whole episode of ec_rollout_mlp_expert_policy: for t = 0 .. n_steps-1, in env
+ * order, every env with coin[t][b] < ratios[t] appends (the observation step t acted on: obs0 for t = 0, else
+ * obs_hist[t-1]; expert_actions[t][b]) -- the ring ends up as n_steps ec_expert_mix calls (or store_expert_data calls,
+ * gail_agent.py:77-83) would leave it.  *written / *n_expert advance by the number appended.
+ *   workspace: ec_expert_append_episode_workspace(n_steps, n_envs) bytes of device memory (contents irrelevant).
+ * Three launches, no host synchronisation. */
+int64_t ec_expert_append_episode_workspace(int32_t n_steps, int64_t n_envs);
+int ec_expert_append_episode(const float* coin, const float* ratios, const int64_t* expert_actions, const float* obs0,
+                             const float* obs_hist, int32_t n_steps, int64_t n_envs, int32_t n_agents, int32_t obs_dim,
+                             int64_t capacity, float* ring_obs, int64_t* ring_actions, int64_t* written, int64_t* n_expert,
+                             void* workspace, void* stream);
 
 /* The tail of a GAIL-discriminator layer -- BatchNorm1d in training mode, ReLU, Dropout(p) (gail_network.py:97-125:
  * fc -> bn -> activation -> dropout) -- over x [rows, C] fp32, C a multiple of 4 with C/4 dividing 256, with the batch

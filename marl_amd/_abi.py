@@ -144,6 +144,7 @@ def lib():
     L.ec_step_random_policy.argtypes = [vp] + [vp] * 8 + [u64, u64, vp, vp]
     L.ec_rollout_random_policy.argtypes = [vp, i32, i32] + [vp] * 8 + [u64, u64, vp, vp]
     L.ec_rollout_mlp_policy.argtypes = [vp, i32] + [vp] * 18
+    L.ec_rollout_mlp_expert_policy.argtypes = [vp, i32] + [vp] * 21
     L.ec_random_policy.argtypes = [vp, i64, i32, u64, u64, vp, vp, vp]
     L.ec_expert_policy.argtypes = [vp, vp, vp, vp]
     L.ec_status.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, vp]
@@ -163,6 +164,9 @@ def lib():
     L.ec_ppo_critic_grad_ex.argtypes = [vp] * 9 + [i64, i32, i32, f32, vp, vp, vp, vp, vp]
     L.ec_gail_disc_grad.argtypes = [vp] * 8 + [i64, i32, i32, i32, f32, vp, vp, vp, vp]
     L.ec_expert_mix.argtypes = [vp] * 5 + [i64, i32, i32, i64] + [vp] * 6
+    L.ec_expert_append_episode.argtypes = [vp] * 5 + [i32, i64, i32, i32, i64] + [vp] * 6
+    L.ec_expert_append_episode_workspace.argtypes = [i32, i64]
+    L.ec_expert_append_episode_workspace.restype = i64
     u64 = C.c_uint64
     L.ec_bn_relu_dropout_fwd.argtypes = [vp, vp, vp, vp, u64, f32, i64, i32, vp, vp]
     L.ec_bn_relu_dropout_bwd_sums.argtypes = [vp, vp, vp, vp, vp, u64, f32, i64, i32, i32, vp, vp]
@@ -174,7 +178,8 @@ def lib():
                "ec_debug_dump", "ec_debug_rng_cursors", "ec_debug_live_tasks", "ec_info", "ec_gae",
                "ec_policy_forward", "ec_gail_reward", "ec_diffusion_reward", "ec_diffusion_grad", "ec_expert_policy",
                "ec_ppo_actor_grad", "ec_ppo_critic_grad", "ec_ppo_actor_grad_ex", "ec_ppo_critic_grad_ex", "ec_gail_disc_grad", "ec_store_transition", "ec_bn_relu_dropout_fwd", "ec_bn_relu_dropout_bwd_sums", "ec_bn_relu_dropout_bwd_dx", "ec_expert_mix", "ec_store_episode", "ec_store_episode_static",
-               "ec_step_random_policy", "ec_rollout_random_policy", "ec_rollout_mlp_policy"):
+               "ec_step_random_policy", "ec_rollout_random_policy", "ec_rollout_mlp_policy",
+               "ec_rollout_mlp_expert_policy", "ec_expert_append_episode"):
         getattr(L, fn).restype = C.c_int
     L.ec_last_error.restype = C.c_char_p
     L.ec_version.restype = C.c_char_p

@@ -72,6 +72,35 @@ class ExpertTransitions:
                        "ec_expert_mix")
         return out
 
+    def append_episode(self, coin, ratios, expert_actions, obs0, obs_hist, n_expert=None):
+        """The appends of a whole episode of env.rollout_mlp_policy(coin=, ratios=) (ec_expert_append_episode): for every
+        step t and env b with coin[t, b] < ratios[t], in (t, b) order, (the observation step t acted on, expert_actions[t, b])
+        — what mix_append / append leave after being called once per step.  coin [T,B], ratios [T], expert_actions [T,B,N],
+        obs0 [B,N,O], obs_hist [T,B,N,O] (observation after step t)."""
+        import ctypes as C
+
+        from marl_amd import _abi
+        T, B, N = expert_actions.shape
+        O = obs0.shape[-1]
+        lib = _abi.lib()
+        need = int(lib.ec_expert_append_episode_workspace(T, B))
+        if getattr(self, "_ws", None) is None or self._ws.numel() < need:
+            self._ws = th.empty(max(need, 4), dtype=th.uint8, device=self.device)
+        for name, t, dtype in (("coin", coin, th.float32), ("ratios", ratios, th.float32), ("obs0", obs0, th.float32),
+                               ("expert_actions", expert_actions, th.int64), ("obs_hist", obs_hist, th.float32)):
+            if t.dtype != dtype or not t.is_contiguous() or t.device != self.obs.device:
+                raise ValueError("%s must be a contiguous %s tensor on %s" % (name, dtype, self.obs.device))
+        if tuple(coin.shape) != (T, B) or tuple(ratios.shape) != (T,) or tuple(obs0.shape) != (B, N, O) \
+                or tuple(obs_hist.shape) != (T, B, N, O) or tuple(self.obs.shape[1:]) != (N, O):
+            raise ValueError("append_episode: shapes do not fit together")
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        with th.cuda.device(self.device):
+            _abi.check(lib.ec_expert_append_episode(vp(coin), vp(ratios), vp(expert_actions), vp(obs0), vp(obs_hist), T, B, N, O,
+                                                    self.capacity, vp(self.obs), vp(self.actions), vp(self._written),
+                                                    vp(n_expert), vp(self._ws),
+                                                    C.c_void_p(th.cuda.current_stream(self.device).cuda_stream)),
+                       "ec_expert_append_episode")
+
     def sample_transitions(self, n, size=None):
         """n distinct transitions, uniformly (np.random.choice(len, n, replace=False) of the reference):
         returns obs [n,N,O], actions [n,N].  `size`: len(self) when the caller already has it (len() synchronises)."""

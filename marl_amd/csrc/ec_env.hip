@@ -1032,6 +1032,80 @@ __device__ __forceinline__ u64 policy_hash(u64 seed, u64 counter, u64 rows, u64 
 // What a main lane of the looping kernel keeps in registers from one step to the next (its queues stay in LDS):
 // with it, the steps between the first and the last of a launch neither stage their state from global memory nor
 // write it back.
+// ------------------------------------------------------------------------------------------ expert policy
+// OptimalAgent._calculate_conservative_score (optimal/optimal_agent.py:211-258) with its four terms (:260-375), in
+// the reference's evaluation order (this file is built without FMA contraction).
+__device__ __forceinline__ double expert_score(const EcDev& d, int nwait, int nexec, int s, int t, double size, double cycles,
+                                               double cons) {
+    const double exec_t = cycles / d.cap[t];
+    double rel = exp(-d.efr[t] * exec_t);  // :260-289
+    double trans_t = 0.0;
+    if (s != t) {
+        trans_t = size / d.rate[s * d.N + t];
+        rel = exp(-d.tfr[s * d.N + t] * trans_t) * rel;
+    }
+    if (rel < 0.85) rel = fmax(0.0, rel - 5.0 * (0.85 - rel));
+    const double qf = 1.5 * cons;  // :291-328
+    const double waiting = nwait * exec_t * qf / (d.k > 1 ? d.k : 1);
+    const double total = (s == t) ? exec_t + waiting : trans_t + exec_t + waiting;
+    const double margin = d.deadline - total;
+    const double required = d.deadline * 0.4 * cons;
+    double time_score = 0.0;
+    if (!(margin < required)) {
+        time_score = fmin(1.0, margin / d.deadline);
+        if (time_score < 0.5) time_score *= 3.0;
+    }
+    const int cur = nwait + nexec;  // :330-353
+    const double max_load = (d.qlen[t] + d.k) * 0.7;
+    double load = 0.0;
+    if (!(cur >= max_load)) {
+        load = 1.0 - cur / max_load;
+        if (cur > 0) load = fmax(0.0, load - cur * 0.2);
+    }
+    const double opt = d.dt * 3;  // :355-375
+    double eff = exec_t <= opt ? 1.0 : fmax(0.2, opt / exec_t);
+    eff += fmin(0.2, d.cores[t] / 32.0);
+    eff = fmin(1.0, eff);
+    if (rel < 0.85) return -INFINITY;  // :235-239
+    if (time_score == 0) return -INFINITY;
+    const double bonus = (s == t) ? 0.3 * cons : 0.0;
+    return 0.6 * rel + 0.25 * time_score + 0.1 * load + 0.05 * eff + bonus;
+}
+
+// OptimalAgent.get_current_optimal_action -> _conservative_action_selection(env, 1.0) (optimal_agent.py:102-120,166-209)
+// for node i holding a new task; a: the node's availability mask [A]; cnt(t, &nwait, &nexec): queue lengths of node t of
+// the same env (global memory in k_expert, the block's LDS copy inside the rollout kernel)
+template <typename CNT>
+__device__ __forceinline__ int expert_decide(const EcDev& d, int i, const int32_t* __restrict__ a, u32 has_new, double size,
+                                             double cycles, CNT cnt) {
+    int last = -1;
+    for (int j = 0; j < d.A; j++)
+        if (a[j]) last = j;
+    if (last < 0 || !has_new) return last >= 0 ? last : d.N;
+    int best = last;
+    double best_score = -INFINITY;
+    int nw, nx;
+    if (a[i]) {
+        cnt(i, nw, nx);
+        const double sc = expert_score(d, nw, nx, i, i, size, cycles, 1.0);
+        if (sc > best_score) {
+            best_score = sc;
+            best = i;
+        }
+    }
+    for (int j = 0; j < last; j++) {  // available_indices[:-1]: every available index but the last one
+        if (!a[j] || j >= d.N || j == i) continue;
+        cnt(j, nw, nx);
+        const double sc = expert_score(d, nw, nx, i, j, size, cycles, 1.0);
+        if (sc > best_score + 0.1 * 1.0) {
+            best_score = sc;
+            best = j;
+        }
+    }
+    return best;
+}
+
+
 template <int KMAX, int DMAX>
 struct StepCarry {
     u32 c0, steps_before, has_new, n_off, ex_n, wq_h, wq_len, wq_min, exA_thr;
@@ -1046,6 +1120,18 @@ struct StepCarry {
     u32 buf_head, buf_len;
 };
 
+// Expert mixing inside the rollout kernel (ec_rollout_mlp_expert_policy; gail_runner.py:72-98, dgail_runner.py:46-94): per
+// env a coin decides whether the step executes the expert's decision or the policy's; the expert's decision of every
+// step is recorded (the FIFO append of the expert-driven envs happens after the launch, from the histories).
+struct ExpertMix {
+    const int32_t* avail;  // [P][A] availability mask of the observation the action is chosen on
+    const float* coin;     // [B] this step's uniform draws
+    float ratio;           // expert iff coin < ratio
+    int64_t* expert_out;   // [P] the expert's decisions of this step
+    u32* s_cnt;            // LDS [main lanes]: waiting | executing << 16 queue lengths of every lane of the block, as the
+                           // previous step left them (the expert scores its neighbours' queues)
+};
+
 // first: the lane's state comes from global memory (else from `cr` and the LDS arrays as the previous step left
 // them); last: it is written back.  One-step launches are both.
 template <int KMAX, int DMAX, bool EVX>
@@ -1053,7 +1139,8 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                                           uint8_t* __restrict__ terminated, int32_t* __restrict__ counters,
                                           float* __restrict__ completion_time, float* __restrict__ next_obs,
                                           int32_t* __restrict__ next_avail, StepPolicy pol, StepCarry<KMAX, DMAX>& cr,
-                                          const bool first, const bool last, const int* s_pick = nullptr) {
+                                          const bool first, const bool last, const int* s_pick = nullptr,
+                                          const ExpertMix* em = nullptr) {
     static_assert(RB_FAIL >= KMAX + DMAX, "failure window too small");
     static_assert(RB_FAIL * 4 >= 12 + 36, "observation scratch does not fit the failure window");
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1373,6 +1460,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
             if (a < ACC_LDS) S.acc[a] = lut_lo[i];
         }
     }
+    if (em && first && L.valid) em->s_cnt[tid] = wq_len | (ex_n << 16);
     EC_STAMP_P(11);
     __syncthreads();
     EC_STAMP(1);
@@ -1385,6 +1473,26 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         if (has_new && action >= 0 && action < N && action != node) {
             slot = d.slot_of[node * N + (int)action];
             rate = d.rate[node * N + (int)action];
+        }
+    }
+
+    if (em && L.valid) {
+        // the expert's decision for this lane (ec_expert_policy's, on the state the previous step left), then the coin
+        const u32* cnt = em->s_cnt + L.env_local * N;
+        const int ea = expert_decide(d, node, em->avail + lane * d.A, has_new, newt.size, newt.cycles, [&](int t, int& nw, int& nx) {
+            const u32 c = cnt[t];
+            nw = (int)(c & 0xffffu);
+            nx = (int)(c >> 16);
+        });
+        em->expert_out[lane] = ea;
+        if (em->coin[L.env] < em->ratio) {
+            action = ea;
+            slot = -1;
+            rate = 0.0;
+            if (has_new && action >= 0 && action < N && action != node) {
+                slot = d.slot_of[node * N + (int)action];
+                rate = d.rate[node * N + (int)action];
+            }
         }
     }
 
@@ -2020,6 +2128,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
             cr.wq_len = wq_len;
             cr.wq_min = wq_min;
             cr.wq_dirty = wq_dirty;
+            if (em) em->s_cnt[tid] = wq_len | (ex_n << 16);  // (read by the next step's expert, past the loop's barrier)
             cr.exA_thr = exA_thr;
             cr.deg = deg;
             cr.cap = cap;
@@ -2232,10 +2341,16 @@ struct MlpRollout {
     unsigned dev_lds;       // byte offset of a block-local copy of the geometry block, or 0: re-read it from global memory
 };
 
-template <int KMAX, int DMAX>
+struct ExpertRollout {
+    const float* coin;     // [n_steps][B]
+    const float* ratios;   // [n_steps]
+    int64_t* expert_hist;  // [n_steps][P]
+};
+
+template <int KMAX, int DMAX, bool EXPERT>
 __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpRollout m, int64_t* actions0, float* reward0,
                                                      uint8_t* terminated0, int32_t* counters0, float* completion_time0,
-                                                     float* next_obs0, int32_t* next_avail0) {
+                                                     float* next_obs0, int32_t* next_avail0, ExpertRollout er) {
     StepCarry<KMAX, DMAX> cr;
 #ifdef EC_STAMPS
     u64 dbg_pol = 0, dbg_wait = 0, dbg_body = 0, dbg_gap = 0, dbg_prev = wall_clock64();
@@ -2244,6 +2359,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
     extern __shared__ __align__(16) unsigned char smem_all[];
     float* s_b23 = reinterpret_cast<float*>(smem_all + m.b23_lds);
     int* s_pick = reinterpret_cast<int*>(s_b23 + polinl::H + 32);  // [main lanes] actions handed over by producer waves
+    u32* s_cnt = reinterpret_cast<u32*>(s_pick + d_mem->nmain);    // [main lanes] queue lengths for the expert (EXPERT)
     for (int i = threadIdx.x; i < polinl::H + 32; i += blockDim.x) s_b23[i] = m.staged[polinl::B2 + i];
     if (m.dev_lds)  // the geometry block, re-read every iteration (see k_step): from LDS it is not a memory round trip
         for (int i = threadIdx.x; i < (int)(sizeof(EcDev) / 16); i += blockDim.x)
@@ -2333,12 +2449,22 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
         const u64 dbg_t2 = dbg_t1;
 #endif
         const int64_t hs = it;
+        ExpertMix emx;
+        const ExpertMix* em = nullptr;
+        if (EXPERT) {
+            emx.avail = it == 0 ? m.avail0 : next_avail0 + (int64_t)(it - 1) * d.P * d.A;
+            emx.coin = er.coin + (int64_t)it * d.B;
+            emx.ratio = er.ratios[it];
+            emx.expert_out = er.expert_hist + (int64_t)it * d.P;
+            emx.s_cnt = s_cnt;
+            em = &emx;
+        }
         step_body<KMAX, DMAX, true>(d, act, reward0 ? reward0 + hs * d.B : nullptr,
                                     terminated0 ? terminated0 + hs * d.B : nullptr,
                                     counters0 ? counters0 + hs * d.B * 4 : nullptr,
                                     completion_time0 ? completion_time0 + hs * d.B : nullptr, next_obs0 + hs * d.P * 9,
                                     next_avail0 + hs * d.P * d.A, StepPolicy{0, 0, nullptr, m.n_steps, 1}, cr, it == 0,
-                                    it + 1 == m.n_steps, split ? s_pick : nullptr);
+                                    it + 1 == m.n_steps, split ? s_pick : nullptr, em);
 #ifdef EC_STAMPS
         dbg_prev = wall_clock64();
         dbg_pol += dbg_t1 - dbg_t0;
@@ -2357,11 +2483,12 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
 #endif
 }
 
-typedef void (*rollout_mlp_fn)(const EcDev*, MlpRollout, int64_t*, float*, uint8_t*, int32_t*, float*, float*, int32_t*);
-rollout_mlp_fn pick_rollout_mlp(int k, int D) {  // the common shapes only: every instantiation is a full step kernel
+typedef void (*rollout_mlp_fn)(const EcDev*, MlpRollout, int64_t*, float*, uint8_t*, int32_t*, float*, float*, int32_t*,
+                               ExpertRollout);
+rollout_mlp_fn pick_rollout_mlp(int k, int D, bool expert) {  // the common shapes only: every instantiation is a full step kernel
     if (k > 4) return nullptr;
-    if (D <= 4) return k_rollout_mlp<4, 4>;
-    if (D <= 8) return k_rollout_mlp<4, 8>;
+    if (D <= 4) return expert ? k_rollout_mlp<4, 4, true> : k_rollout_mlp<4, 4, false>;
+    if (D <= 8) return expert ? k_rollout_mlp<4, 8, true> : k_rollout_mlp<4, 8, false>;
     return nullptr;
 }
 
@@ -2427,81 +2554,24 @@ __global__ void k_random_policy(const int32_t* __restrict__ avail, int64_t rows,
 }
 
 // parity-test helper: one thread serialises env `env`
-// ------------------------------------------------------------------------------------------ expert policy
-// OptimalAgent._calculate_conservative_score (optimal/optimal_agent.py:211-258) with its four terms (:260-375), in
-// the reference's evaluation order (this file is built without FMA contraction).
-__device__ __forceinline__ double expert_score(const EcDev& d, int64_t env_base, int s, int t, double size, double cycles,
-                                               double cons) {
-    const double exec_t = cycles / d.cap[t];
-    double rel = exp(-d.efr[t] * exec_t);  // :260-289
-    double trans_t = 0.0;
-    if (s != t) {
-        trans_t = size / d.rate[s * d.N + t];
-        rel = exp(-d.tfr[s * d.N + t] * trans_t) * rel;
-    }
-    if (rel < 0.85) rel = fmax(0.0, rel - 5.0 * (0.85 - rel));
-    const int nwait = (int)d.wq_len[env_base + t], nexec = (int)d.ex_n[env_base + t];
-    const double qf = 1.5 * cons;  // :291-328
-    const double waiting = nwait * exec_t * qf / (d.k > 1 ? d.k : 1);
-    const double total = (s == t) ? exec_t + waiting : trans_t + exec_t + waiting;
-    const double margin = d.deadline - total;
-    const double required = d.deadline * 0.4 * cons;
-    double time_score = 0.0;
-    if (!(margin < required)) {
-        time_score = fmin(1.0, margin / d.deadline);
-        if (time_score < 0.5) time_score *= 3.0;
-    }
-    const int cur = nwait + nexec;  // :330-353
-    const double max_load = (d.qlen[t] + d.k) * 0.7;
-    double load = 0.0;
-    if (!(cur >= max_load)) {
-        load = 1.0 - cur / max_load;
-        if (cur > 0) load = fmax(0.0, load - cur * 0.2);
-    }
-    const double opt = d.dt * 3;  // :355-375
-    double eff = exec_t <= opt ? 1.0 : fmax(0.2, opt / exec_t);
-    eff += fmin(0.2, d.cores[t] / 32.0);
-    eff = fmin(1.0, eff);
-    if (rel < 0.85) return -INFINITY;  // :235-239
-    if (time_score == 0) return -INFINITY;
-    const double bonus = (s == t) ? 0.3 * cons : 0.0;
-    return 0.6 * rel + 0.25 * time_score + 0.1 * load + 0.05 * eff + bonus;
-}
-
-// OptimalAgent.get_current_optimal_action -> _conservative_action_selection(env, 1.0) (optimal_agent.py:102-120,166-209)
+// (expert policy: expert_score / expert_decide are defined ahead of step_body, which evaluates them inside the rollout kernel)
 __global__ void k_expert(EcDev d, const int32_t* __restrict__ avail, int64_t* __restrict__ actions) {
     const int64_t lane = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= d.P) return;
     const int64_t env = lane / d.N;
     const int i = (int)(lane - env * d.N);
     const int64_t base = env * d.N;
-    const int32_t* a = avail + lane * d.A;
-    int last = -1;
-    for (int j = 0; j < d.A; j++)
-        if (a[j]) last = j;
-    if (last < 0 || !d.has_new[lane]) {
-        actions[lane] = last >= 0 ? last : d.N;
-        return;
+    const u32 has_new = d.has_new[lane];
+    double size = 0.0, cycles = 0.0;
+    if (has_new) {
+        const Rec nt = load_rec(d.newt + lane);
+        size = nt.size;
+        cycles = nt.cycles;
     }
-    const Rec nt = load_rec(d.newt + lane);
-    int best = last;
-    double best_score = -INFINITY;
-    if (a[i]) {
-        const double sc = expert_score(d, base, i, i, nt.size, nt.cycles, 1.0);
-        if (sc > best_score) {
-            best_score = sc;
-            best = i;
-        }
-    }
-    for (int j = 0; j < last; j++) {  // available_indices[:-1]: every available index but the last one
-        if (!a[j] || j >= d.N || j == i) continue;
-        const double sc = expert_score(d, base, i, j, nt.size, nt.cycles, 1.0);
-        if (sc > best_score + 0.1 * 1.0) {
-            best_score = sc;
-            best = j;
-        }
-    }
-    actions[lane] = best;
+    actions[lane] = expert_decide(d, i, avail + lane * d.A, has_new, size, cycles, [&](int t, int& nw, int& nx) {
+        nw = (int)d.wq_len[base + t];
+        nx = (int)d.ex_n[base + t];
+    });
 }
 
 __global__ void k_dump(EcDev d, int64_t env, double* rows, int64_t max_rows, int64_t* n_rows) {
@@ -2581,6 +2651,7 @@ struct ec_env {
     size_t lds_step_multi;   // its dynamic LDS: lds_step + (if it fits) a copy of the geometry block at multi_dev_lds
     unsigned multi_dev_lds;
     rollout_mlp_fn rollout_mlp;  // looping kernel with the Actor inside (ec_rollout_mlp_policy); null if not compiled for k / D
+    rollout_mlp_fn rollout_mlp_expert;  // the same with the expert mixing of the guided runners (ec_rollout_mlp_expert_policy)
     float* d_staged;     // its weight fragments (polinl layout)
     size_t lds_rollout_mlp;
     unsigned mlp_dev_lds;  // LDS offset of the looping kernel's copy of the geometry block (0: none)
@@ -2953,11 +3024,13 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
 #endif
 
     EC_TRY(dev_alloc(h, &h->d_dev, 1));
-    h->rollout_mlp = d.A <= 32 ? pick_rollout_mlp(d.k, D) : nullptr;
+    h->rollout_mlp = d.A <= 32 ? pick_rollout_mlp(d.k, D, false) : nullptr;
+    h->rollout_mlp_expert = (d.A <= 32 && N <= 64) ? pick_rollout_mlp(d.k, D, true) : nullptr;
     h->d_staged = nullptr;
     if (h->rollout_mlp) {
         // + layer-2/3 biases + one action word per main lane (the producer waves' share of the Actor rows)
-        h->lds_rollout_mlp = ((h->lds_step + 15) & ~(size_t)15) + (polinl::H + 32) * sizeof(float) + (size_t)d.nmain * sizeof(int);
+        // (+ another word per main lane: the queue lengths the in-kernel expert reads)
+        h->lds_rollout_mlp = ((h->lds_step + 15) & ~(size_t)15) + (polinl::H + 32) * sizeof(float) + 2 * (size_t)d.nmain * sizeof(int);
         if (h->lds_rollout_mlp > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_rollout_mlp);
         {   // + a copy of the geometry block, if that does not cost a resident block
             int with = 0, without = 0;
@@ -2976,6 +3049,9 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
         }
         EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->rollout_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lds_rollout_mlp));
+        if (h->rollout_mlp_expert)
+            EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->rollout_mlp_expert),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_rollout_mlp));
         EC_TRY(dev_alloc(h, &h->d_staged, (size_t)polinl::staged_floats(N)));
         if (getenv("MARL_AMD_EC_DEBUG")) {
             int per_cu = 0;
@@ -3107,24 +3183,54 @@ int ec_rollout_random_policy(ec_handle h, int32_t n_steps, int32_t keep_history,
                      StepPolicy{seed, counter, next_actions, n_steps, keep_history ? 1 : 0}, stream);
 }
 
+static int rollout_mlp_impl(const char* what, ec_handle h, int32_t n_steps, const float* w1, const float* b1, const float* w2,
+                            const float* b2, const float* w3, const float* b3, const float* uniforms, const float* obs0,
+                            const int32_t* avail0, int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
+                            float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail,
+                            const ExpertRollout* er, void* stream);
+
 int ec_rollout_mlp_policy(ec_handle h, int32_t n_steps, const float* w1, const float* b1, const float* w2, const float* b2,
                           const float* w3, const float* b3, const float* uniforms, const float* obs0,
                           const int32_t* avail0, int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
                           float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail, void* stream) {
-    if (!h) return ec::fail(EC_EINVAL, "ec_rollout_mlp_policy: null handle");
-    if (n_steps < 1) return ec::fail(EC_EINVAL, "ec_rollout_mlp_policy: n_steps = %d", n_steps);
+    return rollout_mlp_impl("ec_rollout_mlp_policy", h, n_steps, w1, b1, w2, b2, w3, b3, uniforms, obs0, avail0, actions, reward,
+                            terminated, counters, completion_time, hop_hist, next_obs, next_avail, nullptr, stream);
+}
+
+int ec_rollout_mlp_expert_policy(ec_handle h, int32_t n_steps, const float* w1, const float* b1, const float* w2,
+                                 const float* b2, const float* w3, const float* b3, const float* uniforms, const float* obs0,
+                                 const int32_t* avail0, const float* coin, const float* ratios, int64_t* actions,
+                                 int64_t* expert_actions, float* reward, uint8_t* terminated, int32_t* counters,
+                                 float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail,
+                                 void* stream) {
+    if (!coin || !ratios || !expert_actions)
+        return ec::fail(EC_EINVAL, "ec_rollout_mlp_expert_policy: coin, ratios and expert_actions are required");
+    const ExpertRollout er{coin, ratios, expert_actions};
+    return rollout_mlp_impl("ec_rollout_mlp_expert_policy", h, n_steps, w1, b1, w2, b2, w3, b3, uniforms, obs0, avail0, actions,
+                            reward, terminated, counters, completion_time, hop_hist, next_obs, next_avail, &er, stream);
+}
+
+static int rollout_mlp_impl(const char* what, ec_handle h, int32_t n_steps, const float* w1, const float* b1, const float* w2,
+                            const float* b2, const float* w3, const float* b3, const float* uniforms, const float* obs0,
+                            const int32_t* avail0, int64_t* actions, float* reward, uint8_t* terminated, int32_t* counters,
+                            float* completion_time, int32_t* hop_hist, float* next_obs, int32_t* next_avail,
+                            const ExpertRollout* er, void* stream) {
+    if (!h) return ec::fail(EC_EINVAL, "%s: null handle", what);
+    if (n_steps < 1) return ec::fail(EC_EINVAL, "%s: n_steps = %d", what, n_steps);
     if (!obs0 || !avail0 || !actions || !next_obs || !next_avail)
-        return ec::fail(EC_EINVAL, "ec_rollout_mlp_policy: obs0, avail0, actions, next_obs and next_avail are required");
-    if (!h->rollout_mlp)
-        return ec::fail(EC_EINVAL, "ec_rollout_mlp_policy is compiled for k <= 4, in-degree <= 8, n_actions <= 32 (have k=%d, A=%d)",
-                        h->d.k, h->d.A);
+        return ec::fail(EC_EINVAL, "%s: obs0, avail0, actions, next_obs and next_avail are required", what);
+    const rollout_mlp_fn fn = er ? h->rollout_mlp_expert : h->rollout_mlp;
+    if (!h->rollout_mlp || !fn)
+        return ec::fail(EC_EINVAL, "%s is compiled for k <= 4, in-degree <= 8, n_actions <= 32 (have k=%d, A=%d)", what, h->d.k,
+                        h->d.A);
     EC_ON_DEVICE(h);
     const int rc = ec::stage_policy(w1, b1, w2, b2, w3, b3, h->d.N, h->d.A, h->d_staged, (hipStream_t)stream);
     if (rc != EC_OK) return rc;
-    hipLaunchKernelGGL(h->rollout_mlp, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_rollout_mlp, (hipStream_t)stream,
-                       h->d_dev, MlpRollout{h->d_staged, uniforms, obs0, avail0, n_steps,
-                                            (unsigned)((h->lds_step + 15) & ~(size_t)15), h->mlp_dev_lds}, actions, reward, terminated,
-                       counters, completion_time, next_obs, next_avail);
+    hipLaunchKernelGGL(fn, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_rollout_mlp, (hipStream_t)stream, h->d_dev,
+                       MlpRollout{h->d_staged, uniforms, obs0, avail0, n_steps, (unsigned)((h->lds_step + 15) & ~(size_t)15),
+                                  h->mlp_dev_lds},
+                       actions, reward, terminated, counters, completion_time, next_obs, next_avail,
+                       er ? *er : ExpertRollout{nullptr, nullptr, nullptr});
     if (hop_hist) {
         const int64_t n = h->d.B * h->d.H;
         hipLaunchKernelGGL(k_copy_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -3214,12 +3320,12 @@ int ec_debug_live_tasks(ec_handle h, int64_t* total_host) {
 
 int ec_info(ec_handle h, int64_t* info_host, int32_t n) {
     if (!h || !info_host) return ec::fail(EC_EINVAL, "null argument");
-    const int64_t v[18] = {h->d.B, h->d.N, h->d.k, h->d.D, h->d.capB, h->d.capR, h->d.capW, h->d.maxTicks,
+    const int64_t v[19] = {h->d.B, h->d.N, h->d.k, h->d.D, h->d.capB, h->d.capR, h->d.capW, h->d.maxTicks,
                            h->threads, h->envs_per_block, (int64_t)(h->state_bytes & 0xffffffffull),
                            (int64_t)(h->state_bytes >> 32), (int64_t)h->lds_step,
                            h->d.epw, h->d.nmain / 64, (h->threads - h->d.nmain) / 64, h->multi_resident ? 1 : 0,
-                           h->rollout_mlp ? 1 : 0};
-    for (int i = 0; i < n && i < 18; i++) info_host[i] = v[i];
+                           h->rollout_mlp ? 1 : 0, (h->rollout_mlp && h->rollout_mlp_expert) ? 1 : 0};
+    for (int i = 0; i < n && i < 19; i++) info_host[i] = v[i];
     return EC_OK;
 }
 

@@ -412,3 +412,121 @@ extern "C" int ec_expert_mix(const float* coin, const float* ratio, const int64_
     EC_HIP(hipGetLastError());
     return EC_OK;
 }
+
+// The same FIFO append for a whole episode of ec_rollout_mlp_expert_policy: step t's expert-driven envs (coin[t][b] <
+// ratios[t]) append (the observation step t acted on, the expert's decision) in (t, b) order.  Appending step by step keeps,
+// per slot, the newest entry that maps to it; so does writing only the entries among the newest `capacity` of the whole
+// episode, which is what happens here, in three launches: per-(step, 256-env chunk) counts, the copy, the counters.
+namespace {
+
+constexpr int EPI_EPB = 256;
+
+struct EpisodeAppendArgs {
+    const float* coin;           // [T][B]
+    const float* ratios;         // [T]
+    const int64_t* expert_hist;  // [T][B,N]
+    const float* obs0;           // [B,N,O] observation step 0 acted on
+    const float* obs_hist;       // [T][B,N,O] observation after step t
+    int T;
+    int64_t B;
+    int N, O;
+    int64_t capacity;
+    float* ring_obs;
+    int64_t* ring_actions;
+    int64_t* written;
+    int64_t* n_expert;  // optional
+    int32_t* counts;    // [T][chunks] workspace
+    int chunks;
+};
+
+__global__ void __launch_bounds__(EPI_EPB) k_expert_episode_count(EpisodeAppendArgs a) {
+    __shared__ int64_t s_red[EPI_EPB / 64];
+    const int t = blockIdx.y;
+    const int64_t b = (int64_t)blockIdx.x * EPI_EPB + threadIdx.x;
+    const int64_t use = (b < a.B && a.coin[(int64_t)t * a.B + b] < a.ratios[t]) ? 1 : 0;
+    const int64_t total = block_sum(use, s_red);
+    if (threadIdx.x == 0) a.counts[t * a.chunks + blockIdx.x] = (int32_t)total;
+}
+
+__global__ void __launch_bounds__(EPI_EPB) k_expert_episode_append(EpisodeAppendArgs a) {
+    __shared__ int64_t s_red[EPI_EPB / 64];
+    __shared__ int64_t s_slot[EPI_EPB];
+    __shared__ int s_wave[EPI_EPB / 64];
+    const int t = blockIdx.y, mine = t * a.chunks + (int)blockIdx.x, n_all = a.T * a.chunks;
+    int64_t before = 0, total = 0;
+    for (int i = threadIdx.x; i < n_all; i += blockDim.x) {
+        const int64_t c = a.counts[i];
+        total += c;
+        before += i < mine ? c : 0;
+    }
+    total = block_sum(total, s_red);
+    before = block_sum(before, s_red);
+    const int64_t own = a.counts[mine];
+    if (own == 0 || before + own <= total - a.capacity) return;  // (block-uniform) nothing selected, or all of it superseded
+    const int64_t written = *a.written;
+    const int64_t b0 = (int64_t)blockIdx.x * EPI_EPB, b = b0 + threadIdx.x;
+    const bool use = b < a.B && a.coin[(int64_t)t * a.B + b] < a.ratios[t];
+    const unsigned long long bal = __ballot(use);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int64_t rank = before + __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; w++) rank += s_wave[w];
+    s_slot[threadIdx.x] = (use && rank >= total - a.capacity) ? (written + rank) % a.capacity : -1;
+    __syncthreads();
+    const int nb = (int)(a.B - b0 < EPI_EPB ? a.B - b0 : EPI_EPB);
+    const int64_t* ex = a.expert_hist + ((int64_t)t * a.B + b0) * a.N;
+    for (int i = threadIdx.x; i < nb * a.N; i += blockDim.x) {
+        const int e = i / a.N, n = i - e * a.N;
+        const int64_t slot = s_slot[e];
+        if (slot >= 0) a.ring_actions[slot * a.N + n] = ex[i];
+    }
+    const int row = a.N * a.O;
+    const float* ob = (t == 0 ? a.obs0 : a.obs_hist + (int64_t)(t - 1) * a.B * row) + b0 * row;
+    for (int i = threadIdx.x; i < nb * row; i += blockDim.x) {
+        const int e = i / row, k = i - e * row;
+        const int64_t slot = s_slot[e];
+        if (slot >= 0) a.ring_obs[slot * row + k] = ob[i];
+    }
+}
+
+// after every block of k_expert_episode_append has read `written`
+__global__ void __launch_bounds__(256) k_expert_episode_commit(EpisodeAppendArgs a) {
+    __shared__ int64_t s_red[4];
+    int64_t total = 0;
+    for (int i = threadIdx.x; i < a.T * a.chunks; i += blockDim.x) total += a.counts[i];
+    total = block_sum(total, s_red);
+    if (threadIdx.x == 0) {
+        *a.written += total;
+        if (a.n_expert) *a.n_expert += total;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t ec_expert_append_episode_workspace(int32_t n_steps, int64_t n_envs) {
+    return n_steps < 0 || n_envs < 0 ? 0 : (int64_t)n_steps * ((n_envs + EPI_EPB - 1) / EPI_EPB) * (int64_t)sizeof(int32_t);
+}
+
+extern "C" int ec_expert_append_episode(const float* coin, const float* ratios, const int64_t* expert_actions, const float* obs0,
+                                        const float* obs_hist, int32_t n_steps, int64_t n_envs, int32_t n_agents,
+                                        int32_t obs_dim, int64_t capacity, float* ring_obs, int64_t* ring_actions,
+                                        int64_t* written, int64_t* n_expert, void* workspace, void* stream) {
+    if (n_envs == 0 || n_steps == 0) return EC_OK;
+    if (!coin || !ratios || !expert_actions || !obs0 || !ring_obs || !ring_actions || !written || !workspace ||
+        (n_steps > 1 && !obs_hist))
+        return ec::fail(EC_EINVAL, "ec_expert_append_episode: null pointer");
+    const int64_t chunks = (n_envs + EPI_EPB - 1) / EPI_EPB;
+    if (n_envs < 0 || n_steps < 0 || n_steps > 65535 || n_agents < 1 || obs_dim < 1 || capacity < 1 ||
+        chunks * n_steps > (int64_t)1 << 24)
+        return ec::fail(EC_EINVAL, "ec_expert_append_episode: n_steps %d, n_envs %lld, n_agents %d, obs_dim %d, capacity %lld",
+                        n_steps, (long long)n_envs, n_agents, obs_dim, (long long)capacity);
+    EpisodeAppendArgs a{coin, ratios, expert_actions, obs0, obs_hist, n_steps, n_envs, n_agents, obs_dim, capacity, ring_obs,
+                        ring_actions, written, n_expert, static_cast<int32_t*>(workspace), (int)chunks};
+    const dim3 grid((unsigned)chunks, (unsigned)n_steps);
+    hipLaunchKernelGGL(k_expert_episode_count, grid, dim3(EPI_EPB), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_expert_episode_append, grid, dim3(EPI_EPB), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_expert_episode_commit, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}

@@ -167,12 +167,15 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
         self._obs_valid = False  # self.obs / self.avail were not written: observe() again before reading them
         return history
 
-    def rollout_mlp_policy(self, params, n_steps, uniforms=None, history=None, want_hops=False):
+    def rollout_mlp_policy(self, params, n_steps, uniforms=None, history=None, want_hops=False, coin=None, ratios=None):
         """n_steps x [Actor forward + mask + softmax + draw on the current observation, env step, next observation] in
         one launch (ec_rollout_mlp_policy): what n_steps rounds of mlp_device.policy_forward + step leave behind,
         bit for bit.  params = mlp_device.linear_params(actor); uniforms [n_steps, B*N] f32 (None: greedy).  The
         current observation is taken from observe() if self.obs is stale.  history: dict of [n_steps, ...] tensors
         as in rollout_random_policy (missing ones are allocated; actions[t] is the action taken AT step t).
+        coin [n_steps, B] f32 + ratios [n_steps] f32 (device): the expert-guided rollout of the GAIL / DGAIL runners
+        (ec_rollout_mlp_expert_policy) — env b executes the expert's decision at step t iff coin[t, b] < ratios[t];
+        history["actions"] then holds the agent's draws and history["expert_actions"] the expert's decisions.
         Returns history."""
         n_steps = int(n_steps)
         B, N = self.n_envs, self.n_agents
@@ -191,6 +194,13 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
                   "counters": ((n_steps, B, 4), th.int32), "completion_time": ((n_steps, B), th.float32),
                   "obs": ((n_steps, B, N, 9), th.float32), "avail": ((n_steps, B, N, N + 1), th.int32),
                   "actions": ((n_steps, B, N), th.int64)}
+        if (coin is None) != (ratios is None):
+            raise ValueError("coin and ratios go together")
+        if coin is not None:
+            for name, t, shape in (("coin", coin, (n_steps, B)), ("ratios", ratios, (n_steps,))):
+                if tuple(t.shape) != shape or t.dtype != th.float32 or not t.is_contiguous() or t.device != self.device:
+                    raise ValueError("%s must be a contiguous float32 %s tensor on the env's device" % (name, shape))
+            shapes["expert_actions"] = ((n_steps, B, N), th.int64)
         history = {} if history is None else history
         for key, (shape, dtype) in shapes.items():
             t = history.get(key)
@@ -198,11 +208,17 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
                 history[key] = th.empty(shape, dtype=dtype, device=self.device)
             elif tuple(t.shape) != shape or t.dtype != dtype or not t.is_contiguous() or t.device != self.device:
                 raise ValueError("history['%s'] must be a contiguous %s tensor of shape %s on the env's device" % (key, dtype, shape))
-        _abi.check(self.lib.ec_rollout_mlp_policy(
-            self._h, n_steps, *[_ptr(t) for t in w], _ptr(uniforms) if uniforms is not None else None, _ptr(self.obs),
-            _ptr(self.avail), _ptr(history["actions"]), _ptr(history["reward"]), _ptr(history["terminated"]),
-            _ptr(history["counters"]), _ptr(history["completion_time"]), _ptr(self.hop_hist) if want_hops else None,
-            _ptr(history["obs"]), _ptr(history["avail"]), self._stream()), "ec_rollout_mlp_policy")
+        head = [self._h, n_steps, *[_ptr(t) for t in w], _ptr(uniforms) if uniforms is not None else None, _ptr(self.obs),
+                _ptr(self.avail)]
+        tail = [_ptr(history["reward"]), _ptr(history["terminated"]), _ptr(history["counters"]),
+                _ptr(history["completion_time"]), _ptr(self.hop_hist) if want_hops else None, _ptr(history["obs"]),
+                _ptr(history["avail"]), self._stream()]
+        if coin is None:
+            _abi.check(self.lib.ec_rollout_mlp_policy(*head, _ptr(history["actions"]), *tail), "ec_rollout_mlp_policy")
+        else:
+            _abi.check(self.lib.ec_rollout_mlp_expert_policy(*head, _ptr(coin), _ptr(ratios), _ptr(history["actions"]),
+                                                             _ptr(history["expert_actions"]), *tail),
+                       "ec_rollout_mlp_expert_policy")
         self._obs_valid = False  # self.obs / self.avail still hold the observation from before the rollout
         return history
 
@@ -264,8 +280,8 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
         return st
 
     def info_geometry(self):
-        v = (C.c_int64 * 18)()
-        _abi.check(self.lib.ec_info(self._h, v, 18), "ec_info")
+        v = (C.c_int64 * 19)()
+        _abi.check(self.lib.ec_info(self._h, v, 19), "ec_info")
         keys = ("B", "N", "k", "D", "cap_buffer", "cap_recv", "cap_wait", "max_ticks", "threads_per_block",
                 "envs_per_block")
         out = {k: int(v[i]) for i, k in enumerate(keys)}
@@ -274,6 +290,7 @@ class BatchedEdgeComputingEnv(MultiAgentEnv):
         out["envs_per_wave"], out["main_waves"], out["rng_producer_waves"] = int(v[13]), int(v[14]), int(v[15])
         out["rollout_kernel_resident"] = bool(v[16])
         out["rollout_mlp_policy"] = bool(v[17])  # ec_rollout_mlp_policy is compiled for this k / in-degree / n_actions
+        out["rollout_mlp_expert_policy"] = bool(v[18])
         return out
 
     def debug_dump(self, env, max_rows=8192):

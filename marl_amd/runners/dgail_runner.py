@@ -6,6 +6,11 @@ runs one).  Per step and per env a coin with the scheduled expert ratio (:30-38,
 expert's action (ec_expert_policy on the device state) or the agent's; the agent's action is what the PPO buffer
 stores either way (:81), and expert-driven envs append (obs, expert action) to the agent's expert store (:93-94).
 `t_env` counts env steps summed over the batch, as ParallelRunner does (parallel_episode_runner.py:103-104).
+
+`args.ec_kernel_rollout` (default on): the whole episode — policy, expert, coin, env step and next observation,
+episode_limit times — is ONE launch (ec_rollout_mlp_expert_policy; ec_rollout_mlp_policy, greedy, in test mode), followed
+by ec_store_episode and ec_expert_append_episode.  The draws of an episode then come from one torch.rand call each for
+the categorical draws and the coins.
 """
 import torch as th
 import torch.distributed as dist
@@ -37,6 +42,41 @@ class DGAILRunner:
         self._ratios = th.ones(args.episode_limit, dtype=th.float32, device=dev)
         self._n_expert = th.zeros((), dtype=th.int64, device=dev)
         self._graphs = {}
+        self._hist = None
+        self._uniforms = self._coin = None
+        self._geometry = None
+
+    def _kernel_rollout_ok(self, test_mode):
+        ag = self.agent
+        if not getattr(self.args, "ec_kernel_rollout", 1) or self.env.device.type != "cuda":
+            return False
+        if not (self._store.usable(ag.buffer) and hasattr(ag, "_fused_ok") and ag._fused_ok()):
+            return False
+        if self._geometry is None:
+            self._geometry = self.env.info_geometry()
+        return self._geometry["rollout_mlp_policy" if test_mode else "rollout_mlp_expert_policy"]
+
+    def _episode_kernel(self, test_mode):
+        """the episode as two or three launches: ec_rollout_mlp[_expert]_policy, ec_store_episode[, ec_expert_append_episode]"""
+        from marl_amd.utils import mlp_device
+        args, env = self.args, self.env
+        B, N, T = args.n_threads, args.n_agents, args.episode_limit
+        if self._uniforms is None:
+            self._uniforms = th.empty(T, B * N, dtype=th.float, device=env.device)
+            self._coin = th.empty(T, B, dtype=th.float, device=env.device)
+        if not test_mode:
+            self._uniforms.uniform_()
+            self._coin.uniform_()
+        guided = not test_mode
+        self._hist = env.rollout_mlp_policy(mlp_device.linear_params(self.agent.policy), T,
+                                            uniforms=None if test_mode else self._uniforms,   # greedy in test mode, :114-126
+                                            history=self._hist, want_hops=True, coin=self._coin if guided else None,
+                                            ratios=self._ratios if guided else None)
+        # env.obs / env.avail still hold the observation from before the first step
+        self._store.episode(self._hist, env.obs, env.avail, None if test_mode else self.agent.buffer)
+        if guided:
+            self.agent.expert_transitions.append_episode(self._coin, self._ratios, self._hist["expert_actions"], env.obs,
+                                                         self._hist["obs"], self._n_expert)
 
     def _ratio_at(self, t_env):
         """dgail_runner.py:30-38"""
@@ -59,7 +99,7 @@ class DGAILRunner:
         # is recorded, and all from the second on replay the hipGraph
         key = bool(test_mode)
         graphed = (getattr(args, "ec_graph_rollout", False) and env.device.type == "cuda"
-                   and self._store.usable(self.agent.buffer))
+                   and self._store.usable(self.agent.buffer) and not self._kernel_rollout_ok(test_mode))
         if graphed and key in self._graphs:
             if self._graphs[key] is None:
                 g = th.cuda.CUDAGraph()
@@ -81,11 +121,17 @@ class DGAILRunner:
     def _episode(self, test_mode):
         args, env = self.args, self.env
         B, N = args.n_threads, args.n_agents
-        self.agent.buffer.reset()
+        kernel = self._kernel_rollout_ok(test_mode)
+        if kernel and not test_mode:
+            self.agent.buffer.t = 0  # ec_store_episode overwrites every element
+        else:
+            self.agent.buffer.reset()
         env.reset()
         env.observe()
         self._totals.zero_()
         self._n_expert.zero_()
+        if kernel:
+            return self._episode_kernel(test_mode)
         n_expert = self._n_expert
         fast = self._store.usable(self.agent.buffer)
         buf = None if test_mode else self.agent.buffer

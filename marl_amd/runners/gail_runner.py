@@ -2,7 +2,12 @@
 environments in lock step.  While `t_expert < expert_guidance_steps` each env flips a coin with the agent's scheduled
 expert ratio (:32-34) and executes the expert's action (ec_expert_policy) or the agent's; the PPO buffer always stores
 an action sampled from the agent (:73-77), expert-driven envs also feed the expert store (:97-98); every training
-episode ends with `agent.update_performance_monitoring` and `agent.train()` (:109-111)."""
+episode ends with `agent.update_performance_monitoring` and `agent.train()` (:109-111).
+
+`args.ec_kernel_rollout` (default on): the whole episode — Actor, expert, coin, env step and next observation,
+episode_limit times — is ONE launch (ec_rollout_mlp_expert_policy; ec_rollout_mlp_policy when the episode is not guided),
+followed by ec_store_episode and, for guided episodes, ec_expert_append_episode.  The draws of an episode then come from
+one torch.rand call each for the categorical draws and the coins."""
 import torch as th
 import torch.distributed as dist
 
@@ -26,6 +31,43 @@ class GAILRunner:
         self._store = TransitionStore(self.env, self._totals)
         self._ratio = th.zeros((), dtype=th.float32, device=dev)   # the episode's expert ratio, on the device
         self._graphs = {}
+        self._hist = None
+        self._uniforms = self._coin = self._ratios = None
+        self._geometry = None
+
+    def _kernel_rollout_ok(self, guided):
+        ag = self.agent
+        if not getattr(self.args, "ec_kernel_rollout", 1) or self.env.device.type != "cuda":
+            return False
+        if not (self._store.usable(ag.buffer) and hasattr(ag, "_fused_ok") and ag._fused_ok()):
+            return False
+        if self._geometry is None:
+            self._geometry = self.env.info_geometry()
+        return self._geometry["rollout_mlp_expert_policy" if guided else "rollout_mlp_policy"]
+
+    def _episode_kernel(self, test_mode, guided):
+        """the episode as two or three launches: ec_rollout_mlp[_expert]_policy, ec_store_episode[, ec_expert_append_episode]"""
+        from marl_amd.utils import mlp_device
+        args, env = self.args, self.env
+        B, N, T = args.n_threads, args.n_agents, args.episode_limit
+        if self._uniforms is None:
+            self._uniforms = th.empty(T, B * N, dtype=th.float, device=env.device)
+            self._coin = th.empty(T, B, dtype=th.float, device=env.device)
+            self._ratios = th.empty(T, dtype=th.float, device=env.device)
+        if not test_mode:
+            self._uniforms.uniform_()
+        if guided:
+            self._coin.uniform_()
+            self._ratios.copy_(self._ratio.expand(T))
+        self._hist = env.rollout_mlp_policy(mlp_device.linear_params(self.agent.actor), T,
+                                            uniforms=None if test_mode else self._uniforms,   # greedy in test mode (:46-59)
+                                            history=self._hist, want_hops=True, coin=self._coin if guided else None,
+                                            ratios=self._ratios if guided else None)
+        # env.obs / env.avail still hold the observation from before the first step
+        self._store.episode(self._hist, env.obs, env.avail, None if test_mode else self.agent.buffer)
+        if guided:
+            self.agent.expert_transitions.append_episode(self._coin, self._ratios, self._hist["expert_actions"], env.obs,
+                                                         self._hist["obs"])
 
     def run(self, test_mode=False, t_expert=0):
         args, env = self.args, self.env
@@ -37,7 +79,7 @@ class GAILRunner:
         # is recorded, and all from the second on replay the hipGraph
         key = (bool(test_mode), bool(guided))
         graphed = (getattr(args, "ec_graph_rollout", False) and env.device.type == "cuda"
-                   and self._store.usable(self.agent.buffer))
+                   and self._store.usable(self.agent.buffer) and not self._kernel_rollout_ok(guided))
         if graphed and key in self._graphs:
             if self._graphs[key] is None:
                 g = th.cuda.CUDAGraph()
@@ -59,10 +101,16 @@ class GAILRunner:
     def _episode(self, test_mode, guided):
         args, env = self.args, self.env
         B, N = args.n_threads, args.n_agents
-        self.agent.buffer.reset()
+        kernel = self._kernel_rollout_ok(guided)
+        if kernel and not test_mode:
+            self.agent.buffer.t = 0  # ec_store_episode overwrites every element
+        else:
+            self.agent.buffer.reset()
         env.reset()
         env.observe()
         self._totals.zero_()
+        if kernel:
+            return self._episode_kernel(test_mode, guided)
         fast = self._store.usable(self.agent.buffer)
         buf = None if test_mode else self.agent.buffer
         if fast and buf is not None:

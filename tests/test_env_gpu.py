@@ -467,6 +467,71 @@ def test_rollout_mlp_policy_launch_geometries(monkeypatch, epw, mw, producers):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,chunk,geometry", [(64, 7, None), (33, 100, None), (37, 25, (6, 1, 1)), (37, 25, (2, 2, 1)),
+                                               (37, 25, (3, 1, 0)), (37, 25, (1, 4, 0))])
+def test_rollout_mlp_expert_policy_equals_per_step_launches(monkeypatch, B, chunk, geometry):
+    """ec_rollout_mlp_expert_policy (Actor, expert, coin and env step, n steps in one launch) == n rounds of
+    ec_policy_forward + ec_expert_policy + where(coin < ratio) + ec_step on the same weights, uniforms and coins: the
+    agent's draws, the expert's decisions, every step output and the final env state, bit for bit, over an episode
+    boundary, with ragged chunking and under the launch geometries of the test above.  Ratios sweep 1 -> 0."""
+    th = _th()
+    from marl_amd.utils import mlp_device
+    g = load_golden("env10")
+    args = args_from_golden(g)
+    N, T = args.edge_node_num, args.episode_limit
+    ref_env = _make_env(args, B, 3)
+    if geometry:
+        for key, v in zip(("MARL_AMD_EC_EPW", "MARL_AMD_EC_MW", "MARL_AMD_EC_PRODUCERS"), geometry):
+            monkeypatch.setenv(key, str(v))
+    env = _make_env(args, B, 3)
+    geo = env.info_geometry()
+    assert geo["rollout_mlp_expert_policy"]
+    if geometry:
+        assert (geo["envs_per_wave"], geo["main_waves"], geo["rng_producer_waves"] > 0) == geometry[:2] + (bool(geometry[2]),)
+    dev = env.device
+    gen = th.Generator().manual_seed(4321)
+    dims = [(64, 9 + N), (64,), (64, 64), (64,), (N + 1, 64), (N + 1,)]
+    params = tuple((th.randn(*d, generator=gen) * (0.6 if len(d) == 2 else 0.2)).to(dev) for d in dims)
+    n_expert = n_agent = n_differ = 0
+    for ep in range(2):
+        for e in (ref_env, env):
+            e.reset()
+            e.observe()
+        t = 0
+        while t < T:
+            k = min(chunk, T - t)
+            u = th.rand(k, B * N, generator=gen).to(dev)
+            coin = th.rand(k, B, generator=gen).to(dev)
+            ratios = th.linspace(1.0, 0.0, k).to(dev) if k > 1 else th.full((1,), 0.5, device=dev)
+            ref = {key: [] for key in ("reward", "terminated", "counters", "completion_time", "obs", "avail", "actions",
+                                       "expert_actions")}
+            for i in range(k):
+                _, _, a = mlp_device.policy_forward(params, ref_env.obs, N, ref_env.avail, u[i], want_probs=False)
+                a = a.view(B, N)
+                ex = ref_env.expert_actions()
+                use = coin[i] < ratios[i]
+                run = th.where(use.unsqueeze(-1), ex, a)
+                n_expert += int(use.sum())
+                n_agent += int((~use).sum())
+                n_differ += int((ex != a).any(-1).sum())
+                r, term, info = ref_env.step(run)
+                for key, val in (("reward", r), ("terminated", term), ("counters", info["counters"]),
+                                 ("completion_time", info["task_completion_time"]), ("obs", ref_env.obs),
+                                 ("avail", ref_env.avail), ("actions", a), ("expert_actions", ex)):
+                    ref[key].append(val.clone())
+            hist = env.rollout_mlp_policy(params, k, uniforms=u, coin=coin, ratios=ratios)
+            for key in ref:
+                assert th.equal(th.stack(ref[key]), hist[key]), (ep, t, key)
+            t += k
+    assert n_expert > 100 and n_agent > 100 and n_differ > 100   # both branches ran, and they differ
+    assert np.array_equal(ref_env.debug_dump(B - 1), env.debug_dump(B - 1))
+    assert np.array_equal(ref_env.debug_rng_cursors(), env.debug_rng_cursors())
+    for e in (ref_env, env):
+        assert e.status() & ~32 == 0
+        e.close()
+
+
+@pytest.mark.gpu
 def test_rollout_mlp_policy_unsupported_shape_is_an_error():
     """40 nodes = 41 actions: outside what the in-kernel Actor is compiled for; the entry point says so (the runner
     keeps the per-step launches there)."""

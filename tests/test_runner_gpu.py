@@ -209,7 +209,7 @@ def test_imitation_runner_graph_rollout(kind):
     from marl_amd.agent_register import agent_register
     from marl_amd.runners.runner_register import runner_register
     B = 24
-    a = _imitation_args(kind, B, episode_limit=30, ec_graph_rollout=1)
+    a = _imitation_args(kind, B, episode_limit=30, ec_graph_rollout=1, ec_kernel_rollout=0)  # (the kernel rollout has nothing to replay)
     th.manual_seed(4)
     agent = agent_register[kind](a)
     if kind == "dgail":
@@ -646,3 +646,34 @@ def test_expert_mix_equals_torch_append(B, cap, ratio):
         k = len(ref)
         assert len(got) == k
         assert th.equal(got.obs[:cap], ref.obs[:cap]) and th.equal(got.actions[:cap], ref.actions[:cap]), step
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,cap,ratio", [(37, 5, 1000, 0.5), (300, 7, 64, 0.6), (700, 3, 10_000, 1.0), (513, 4, 100, 0.02),
+                                           (64, 6, 50, 0.0)])
+def test_expert_append_episode_equals_per_step_appends(B, T, cap, ratio):
+    """ec_expert_append_episode (the FIFO appends of a whole kernel rollout) leaves the ring as T per-step append() calls
+    do: wrap-around, more selected rows than the ring holds, several 256-env chunks, nothing selected; twice in a row."""
+    import torch as th
+    from marl_amd.buffer.expert_transitions import ExpertTransitions
+    dev = th.device("cuda:0")
+    N, O = 10, 9
+    gen = th.Generator().manual_seed(B * 31 + T)
+    a, b = ExpertTransitions(cap, N, O, dev), ExpertTransitions(cap, N, O, dev)
+    n_a = th.zeros((), dtype=th.int64, device=dev)
+    total = 0
+    for rep in range(2):
+        coin = th.rand(T, B, generator=gen).to(dev)
+        ratios = (th.full((T,), ratio) * th.linspace(1.0, 0.5, T)).to(dev)
+        obs0 = th.randn(B, N, O, generator=gen).to(dev)
+        obs_hist = th.randn(T, B, N, O, generator=gen).to(dev)
+        ex = th.randint(0, N + 1, (T, B, N), generator=gen).to(dev)
+        for t in range(T):
+            use = coin[t] < ratios[t]
+            b.append(obs0 if t == 0 else obs_hist[t - 1], ex[t], use)
+            total += int(use.sum())
+        a.append_episode(coin, ratios, ex, obs0, obs_hist, n_a)
+        assert int(a._written) == int(b._written) == total == int(n_a)
+        n = len(b)
+        assert len(a) == n
+        assert th.equal(a.obs[:n], b.obs[:n]) and th.equal(a.actions[:n], b.actions[:n]), rep
