@@ -30,7 +30,7 @@ inline int fail(int code, const char* fmt, ...) {
     } while (0)
 
 // ec_mlp.hip: the Actor's weights in the fragment order of ec_policy_inline.h (one small launch), for the looping
-// env kernel of ec_rollout_mlp_policy.  dst holds polinl::staged_floats(n_agents) floats.
+// env kernel of ec_rollout_mlp_policy.  dst holds polinl::staged_floats(n_agents, n_actions <= 32 ? 1 : 2) floats.
 int stage_policy(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                  int n_agents, int n_actions, float* dst, hipStream_t stream);
 

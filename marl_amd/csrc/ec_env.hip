@@ -1075,17 +1075,37 @@ __device__ __forceinline__ double expert_score(const EcDev& d, int nwait, int ne
 // OptimalAgent.get_current_optimal_action -> _conservative_action_selection(env, 1.0) (optimal_agent.py:102-120,166-209)
 // for node i holding a new task; a: the node's availability mask [A]; cnt(t, &nwait, &nexec): queue lengths of node t of
 // the same env (global memory in k_expert, the block's LDS copy inside the rollout kernel)
+// bits [64 w, 64 w + 64) of an availability row as a mask; the loads of a chunk are independent, so they overlap (a
+// one-element-per-iteration loop pays one memory round trip per action: 41 of them at 40 nodes)
+__device__ __forceinline__ u64 avail_word(const int32_t* __restrict__ a, int A, int w) {
+    u64 m = 0;
+    const int hi = A - 64 * w < 64 ? A - 64 * w : 64;
+    for (int j0 = 0; j0 < hi; j0 += 8) {
+        int32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = j0 + u < hi ? a[64 * w + j0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) m |= (u64)(v[u] != 0) << (j0 + u);
+    }
+    return m;
+}
+
 template <typename CNT>
 __device__ __forceinline__ int expert_decide(const EcDev& d, int i, const int32_t* __restrict__ a, u32 has_new, double size,
                                              double cycles, CNT cnt) {
+    const int nwords = (d.A + 63) >> 6;
     int last = -1;
-    for (int j = 0; j < d.A; j++)
-        if (a[j]) last = j;
+    u64 m0 = 0;
+    for (int w = 0; w < nwords; w++) {
+        const u64 m = avail_word(a, d.A, w);
+        if (w == 0) m0 = m;
+        if (m) last = 64 * w + 63 - __clzll((long long)m);
+    }
     if (last < 0 || !has_new) return last >= 0 ? last : d.N;
     int best = last;
     double best_score = -INFINITY;
     int nw, nx;
-    if (a[i]) {
+    if (i < 64 ? (m0 >> i) & 1ull : (avail_word(a, d.A, i >> 6) >> (i & 63)) & 1ull) {
         cnt(i, nw, nx);
         const double sc = expert_score(d, nw, nx, i, i, size, cycles, 1.0);
         if (sc > best_score) {
@@ -1093,13 +1113,19 @@ __device__ __forceinline__ int expert_decide(const EcDev& d, int i, const int32_
             best = i;
         }
     }
-    for (int j = 0; j < last; j++) {  // available_indices[:-1]: every available index but the last one
-        if (!a[j] || j >= d.N || j == i) continue;
-        cnt(j, nw, nx);
-        const double sc = expert_score(d, nw, nx, i, j, size, cycles, 1.0);
-        if (sc > best_score + 0.1 * 1.0) {
-            best_score = sc;
-            best = j;
+    for (int w = 0; w < nwords; w++) {  // available_indices[:-1]: every available index but the last one, ascending
+        u64 m = w == 0 ? m0 : avail_word(a, d.A, w);
+        while (m) {
+            const int j = 64 * w + __builtin_ctzll(m);
+            m &= m - 1;
+            if (j >= last) break;
+            if (j >= d.N || j == i) continue;
+            cnt(j, nw, nx);
+            const double sc = expert_score(d, nw, nx, i, j, size, cycles, 1.0);
+            if (sc > best_score + 0.1 * 1.0) {
+                best_score = sc;
+                best = j;
+            }
         }
     }
     return best;
@@ -2347,7 +2373,21 @@ struct ExpertRollout {
     int64_t* expert_hist;  // [n_steps][P]
 };
 
-template <int KMAX, int DMAX, bool EXPERT>
+// TO3: output tiles of the Actor's last layer (1: up to 32 actions, 2: up to 64)
+template <int TO3, int G>
+__device__ __forceinline__ int rollout_policy_rows(const float* __restrict__ st, const float* s_b23, const float* __restrict__ obs,
+                                                   const int32_t* __restrict__ avail, const float* __restrict__ uniforms,
+                                                   int64_t* __restrict__ actions, int64_t row0, int cnt, int n_agents, int A,
+                                                   int lane) {
+    if constexpr (TO3 == 1)
+        return A <= 16 ? polinl::policy_rows<2, G>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane)
+                       : polinl::policy_rows<4, G>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane);
+    else
+        return A <= 48 ? polinl::policy_rows<6, G, 2>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane)
+                       : polinl::policy_rows<8, G, 2>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane);
+}
+
+template <int KMAX, int DMAX, bool EXPERT, int TO3>
 __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpRollout m, int64_t* actions0, float* reward0,
                                                      uint8_t* terminated0, int32_t* counters0, float* completion_time0,
                                                      float* next_obs0, int32_t* next_avail0, ExpertRollout er) {
@@ -2358,9 +2398,9 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
 #endif
     extern __shared__ __align__(16) unsigned char smem_all[];
     float* s_b23 = reinterpret_cast<float*>(smem_all + m.b23_lds);
-    int* s_pick = reinterpret_cast<int*>(s_b23 + polinl::H + 32);  // [main lanes] actions handed over by producer waves
+    int* s_pick = reinterpret_cast<int*>(s_b23 + polinl::H + 32 * TO3);  // [main lanes] actions handed over by producer waves
     u32* s_cnt = reinterpret_cast<u32*>(s_pick + d_mem->nmain);    // [main lanes] queue lengths for the expert (EXPERT)
-    for (int i = threadIdx.x; i < polinl::H + 32; i += blockDim.x) s_b23[i] = m.staged[polinl::B2 + i];
+    for (int i = threadIdx.x; i < polinl::H + 32 * TO3; i += blockDim.x) s_b23[i] = m.staged[polinl::off_B2(TO3) + i];
     if (m.dev_lds)  // the geometry block, re-read every iteration (see k_step): from LDS it is not a memory round trip
         for (int i = threadIdx.x; i < (int)(sizeof(EcDev) / 16); i += blockDim.x)
             reinterpret_cast<u32x4*>(smem_all + m.dev_lds)[i] = reinterpret_cast<const u32x4*>(d_mem)[i];
@@ -2426,19 +2466,16 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
                 int cnt = nrows - r0 < per ? nrows - r0 : per;
                 if (split && cnt > 32) cnt = 32;
                 if (cnt > 32) {
-                    pick = d.A <= 16 ? polinl::policy_rows<2, 2>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane)
-                                     : polinl::policy_rows<4, 2>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
+                    pick = rollout_policy_rows<TO3, 2>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
                 } else if (cnt > 0) {
-                    pick = d.A <= 16 ? polinl::policy_rows<2, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane)
-                                     : polinl::policy_rows<4, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
+                    pick = rollout_policy_rows<TO3, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
                 }
             } else if (split) {
                 for (int w = wave - nmw; w < nmw; w += npw) {  // the remainders of main waves w, w + npw, ...
                     const int r0 = w * per + 32;
                     const int cnt = nrows - r0 < per - 32 ? nrows - r0 : per - 32;
                     if (cnt <= 0) continue;
-                    const int pk = d.A <= 16 ? polinl::policy_rows<2, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane)
-                                             : polinl::policy_rows<4, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
+                    const int pk = rollout_policy_rows<TO3, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
                     if (lane < cnt) s_pick[r0 + lane] = pk;  // index = the taking lane's slot (lane_id_main: w * per + l)
                 }
             }
@@ -2485,10 +2522,12 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
 
 typedef void (*rollout_mlp_fn)(const EcDev*, MlpRollout, int64_t*, float*, uint8_t*, int32_t*, float*, float*, int32_t*,
                                ExpertRollout);
-rollout_mlp_fn pick_rollout_mlp(int k, int D, bool expert) {  // the common shapes only: every instantiation is a full step kernel
-    if (k > 4) return nullptr;
-    if (D <= 4) return expert ? k_rollout_mlp<4, 4, true> : k_rollout_mlp<4, 4, false>;
-    if (D <= 8) return expert ? k_rollout_mlp<4, 8, true> : k_rollout_mlp<4, 8, false>;
+rollout_mlp_fn pick_rollout_mlp(int k, int D, int A, bool expert) {  // the common shapes only: every instantiation is a full step kernel
+    if (k > 4 || A > 64) return nullptr;
+    if (A > 32)  // 33..64 actions (the 40-node topology of BASELINE configs[4]): in-degree <= 4 only
+        return D > 4 ? nullptr : (expert ? k_rollout_mlp<4, 4, true, 2> : k_rollout_mlp<4, 4, false, 2>);
+    if (D <= 4) return expert ? k_rollout_mlp<4, 4, true, 1> : k_rollout_mlp<4, 4, false, 1>;
+    if (D <= 8) return expert ? k_rollout_mlp<4, 8, true, 1> : k_rollout_mlp<4, 8, false, 1>;
     return nullptr;
 }
 
@@ -3024,13 +3063,13 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
 #endif
 
     EC_TRY(dev_alloc(h, &h->d_dev, 1));
-    h->rollout_mlp = d.A <= 32 ? pick_rollout_mlp(d.k, D, false) : nullptr;
-    h->rollout_mlp_expert = (d.A <= 32 && N <= 64) ? pick_rollout_mlp(d.k, D, true) : nullptr;
+    h->rollout_mlp = pick_rollout_mlp(d.k, D, d.A, false);
+    h->rollout_mlp_expert = pick_rollout_mlp(d.k, D, d.A, true);
     h->d_staged = nullptr;
     if (h->rollout_mlp) {
         // + layer-2/3 biases + one action word per main lane (the producer waves' share of the Actor rows)
         // (+ another word per main lane: the queue lengths the in-kernel expert reads)
-        h->lds_rollout_mlp = ((h->lds_step + 15) & ~(size_t)15) + (polinl::H + 32) * sizeof(float) + 2 * (size_t)d.nmain * sizeof(int);
+        h->lds_rollout_mlp = ((h->lds_step + 15) & ~(size_t)15) + (polinl::H + 64) * sizeof(float) + 2 * (size_t)d.nmain * sizeof(int);
         if (h->lds_rollout_mlp > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_rollout_mlp);
         {   // + a copy of the geometry block, if that does not cost a resident block
             int with = 0, without = 0;
@@ -3052,7 +3091,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
         if (h->rollout_mlp_expert)
             EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->rollout_mlp_expert),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_rollout_mlp));
-        EC_TRY(dev_alloc(h, &h->d_staged, (size_t)polinl::staged_floats(N)));
+        EC_TRY(dev_alloc(h, &h->d_staged, (size_t)polinl::staged_floats(N, 2)));
         if (getenv("MARL_AMD_EC_DEBUG")) {
             int per_cu = 0;
             EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(h->rollout_mlp),
@@ -3221,8 +3260,8 @@ static int rollout_mlp_impl(const char* what, ec_handle h, int32_t n_steps, cons
         return ec::fail(EC_EINVAL, "%s: obs0, avail0, actions, next_obs and next_avail are required", what);
     const rollout_mlp_fn fn = er ? h->rollout_mlp_expert : h->rollout_mlp;
     if (!h->rollout_mlp || !fn)
-        return ec::fail(EC_EINVAL, "%s is compiled for k <= 4, in-degree <= 8, n_actions <= 32 (have k=%d, A=%d)", what, h->d.k,
-                        h->d.A);
+        return ec::fail(EC_EINVAL, "%s is compiled for k <= 4 and in-degree <= 8 with n_actions <= 32 or in-degree <= 4 with "
+                        "n_actions <= 64 (have k=%d, D=%d, A=%d)", what, h->d.k, h->d.D, h->d.A);
     EC_ON_DEVICE(h);
     const int rc = ec::stage_policy(w1, b1, w2, b2, w3, b3, h->d.N, h->d.A, h->d_staged, (hipStream_t)stream);
     if (rc != EC_OK) return rc;

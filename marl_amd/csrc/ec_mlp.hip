@@ -159,20 +159,20 @@ k_policy(const float* __restrict__ w1, const float* __restrict__ b1, const float
 __global__ void __launch_bounds__(NT)
 k_stage_policy(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3, int n_agents, int A,
-               float* __restrict__ dst) {
+               int to3, float* __restrict__ dst) {
     static_assert(polinl::OBS == OBS && polinl::H == H, "ec_policy_inline.h is for the same net");
     const int in1 = OBS + n_agents;
     stage_frag(dst + polinl::F1, w1, in1, 1, H, OBS, 8, 2, false);
     stage_frag(dst + polinl::F2, w2, H, 1, H, H, 32, 2, true);
-    stage_frag(dst + polinl::F3, w3, H, 1, A, H, 32, 1, true);
+    stage_frag(dst + polinl::F3, w3, H, 1, A, H, 32, to3, true);
     for (int i = threadIdx.x; i < H; i += blockDim.x) {
-        dst[polinl::B1 + i] = b1[i];
-        dst[polinl::B2 + i] = b2[i];
+        dst[polinl::off_B1(to3) + i] = b1[i];
+        dst[polinl::off_B2(to3) + i] = b2[i];
     }
-    for (int i = threadIdx.x; i < 32; i += blockDim.x) dst[polinl::B3 + i] = i < A ? b3[i] : 0.0f;
+    for (int i = threadIdx.x; i < 32 * to3; i += blockDim.x) dst[polinl::off_B3(to3) + i] = i < A ? b3[i] : 0.0f;
     for (int i = threadIdx.x; i < n_agents * H; i += blockDim.x) {
         const int ag = i / H, o = i - ag * H;
-        dst[polinl::BI + i] = b1[o] + w1[(size_t)o * in1 + OBS + ag];  // k_policy: acc = b1; acc += column
+        dst[polinl::off_BI(to3) + i] = b1[o] + w1[(size_t)o * in1 + OBS + ag];  // k_policy: acc = b1; acc += column
     }
 }
 
@@ -499,9 +499,10 @@ int blocks_per_cu(size_t lds) {
 int ec::stage_policy(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                      int n_agents, int n_actions, float* dst, hipStream_t stream) {
     if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !dst) return ec::fail(EC_EINVAL, "stage_policy: null weights");
-    if (n_actions < 1 || n_actions > 32 || n_agents < 1)
-        return ec::fail(EC_EINVAL, "in-kernel policy: n_actions = %d (supported: 1..32)", n_actions);
-    hipLaunchKernelGGL(k_stage_policy, dim3(1), dim3(NT), 0, stream, w1, b1, w2, b2, w3, b3, n_agents, n_actions, dst);
+    if (n_actions < 1 || n_actions > 64 || n_agents < 1)
+        return ec::fail(EC_EINVAL, "in-kernel policy: n_actions = %d (supported: 1..64)", n_actions);
+    hipLaunchKernelGGL(k_stage_policy, dim3(1), dim3(NT), 0, stream, w1, b1, w2, b2, w3, b3, n_agents, n_actions,
+                       n_actions <= 32 ? 1 : 2, dst);
     EC_HIP(hipGetLastError());
     return EC_OK;
 }

@@ -20,12 +20,13 @@ constexpr int OBS = 9, H = 64;
 // float offsets inside the staged block (ec::stage_policy writes it)
 constexpr int F1 = 0;                 // layer 1 fragments: 8 steps x 2 tiles x 64 lanes
 constexpr int F2 = F1 + 8 * 2 * 64;   // layer 2: 32 steps x 2 tiles
-constexpr int F3 = F2 + 32 * 2 * 64;  // layer 3: 32 steps x 1 tile (n_actions <= 32)
-constexpr int B1 = F3 + 32 * 1 * 64;
-constexpr int B2 = B1 + H;
-constexpr int B3 = B2 + H;            // [32], zero beyond n_actions
-constexpr int BI = B3 + 32;           // [n_agents][64]: b1 + the agent's one-hot column of W1 (the bias an agent's rows start from)
-__host__ __device__ constexpr int staged_floats(int n_agents) { return BI + n_agents * H; }
+constexpr int F3 = F2 + 32 * 2 * 64;  // layer 3: 32 steps x TO3 tiles (TO3 = 1: n_actions <= 32, TO3 = 2: <= 64)
+__host__ __device__ constexpr int off_B1(int to3) { return F3 + 32 * to3 * 64; }
+__host__ __device__ constexpr int off_B2(int to3) { return off_B1(to3) + H; }
+__host__ __device__ constexpr int off_B3(int to3) { return off_B2(to3) + H; }        // [32 TO3], zero beyond n_actions
+__host__ __device__ constexpr int off_BI(int to3) { return off_B3(to3) + 32 * to3; }  // [n_agents][64]: b1 + the agent's one-hot column of W1 (the bias an agent's rows start from)
+constexpr int B1 = off_B1(1), B2 = off_B2(1), B3 = off_B3(1), BI = off_BI(1);
+__host__ __device__ constexpr int staged_floats(int n_agents, int to3 = 1) { return off_BI(to3) + n_agents * H; }
 
 __device__ __forceinline__ float relu(float x) { return x > 0.0f ? x : 0.0f; }
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
@@ -84,8 +85,10 @@ __device__ __forceinline__ void hidden_part(f32x16 (&out)[TO], const Frag<NW>& w
 
 // The Actor on rows row0 .. row0+cnt-1 (cnt <= 32 G) of obs [rows, 9] / avail [rows, A] by one full wave; lane l
 // returns the action of row row0 + l (and writes it to actions[row0 + l]); -1 beyond cnt.  uniforms: one per row for
-// the inverse-CDF draw, or null for the greedy choice.  A <= 8 NQ <= 32.  s_b23: the biases of layers 2 and 3
-// ([64] + [32]) in LDS.
+// the inverse-CDF draw, or null for the greedy choice.  A <= 8 NQ <= 32 TO3.  s_b23: the biases of layers 2 and 3
+// ([64] + [32 TO3]) in LDS.  TO3 = 2 (33..64 actions): layer 3 has two output tiles; its fragments are fetched per group,
+// in two halves, and the mask / uniform after the matrix work — the registers of the wide epilogue (x[8 NQ], av[8 NQ])
+// leave no room to hold them across it, and a round trip is small next to a 40-node env step.
 // A memory round trip costs ~2 us next to the env step's traffic, several times the 106 MFMAs of a 32-row group, so
 // the order of things is about round trips: the fragments of layers 1 and 2, the observation inputs and the first
 // layer's bias (+ agent-id column, one precombined vector per agent) of BOTH groups are requested up front in one
@@ -93,7 +96,7 @@ __device__ __forceinline__ void hidden_part(f32x16 (&out)[TO], const Frag<NW>& w
 // memory.  Scheduling barriers pin that order (left alone, the compiler hoists every load to the top and spills a
 // hundred registers per lane to scratch).  G = 2 runs its two 32-row groups one after the other on the same
 // fragments.
-template <int NQ, int G>
+template <int NQ, int G, int TO3 = 1>
 __device__ __forceinline__ int policy_rows(const float* __restrict__ st, const float* s_b23,
                                            const float* __restrict__ obs, const int32_t* __restrict__ avail,
                                            const float* __restrict__ uniforms, int64_t* __restrict__ actions,
@@ -115,7 +118,7 @@ __device__ __forceinline__ int policy_rows(const float* __restrict__ st, const f
             const int k = 2 * s + half;
             b[g][s] = (live && k < OBS) ? obs[row * OBS + k] : 0.0f;
         }
-        acc_load<2>(h1[g], st + BI + agent * H, half, false);
+        acc_load<2>(h1[g], st + off_BI(TO3) + agent * H, half, false);
     }
     w2.load(st + F2, 0, lane);
     __builtin_amdgcn_sched_barrier(0);
@@ -137,24 +140,34 @@ __device__ __forceinline__ int policy_rows(const float* __restrict__ st, const f
     __builtin_amdgcn_sched_barrier(0);
     // second round, behind layer 2 of the first group: layer 3's fragments and the epilogue's inputs.  Lane l is the
     // lane of row row0 + l (G = 2); lanes 0..31 those of the only group (G = 1)
-    w3.load(st + F3, 0, lane);
+    if constexpr (TO3 == 1) w3.load(st + F3, 0, lane);
     const bool mine = G == 2 ? lane < cnt : (!half && jrow < cnt);
     const int64_t myrow = row0 + (mine ? lane : 0);
     int32_t av[8 * NQ];
     float u01 = 0.0f;
+    if constexpr (TO3 == 1) {
 #pragma unroll
-    for (int a = 0; a < 8 * NQ; a++) av[a] = (mine && a < A) ? avail[myrow * A + a] : 1;
-    if (uniforms && mine) u01 = uniforms[myrow];
+        for (int a = 0; a < 8 * NQ; a++) av[a] = (mine && a < A) ? avail[myrow * A + a] : 1;
+        if (uniforms && mine) u01 = uniforms[myrow];
+    }
     __builtin_amdgcn_sched_barrier(0);
     float x[8 * NQ];
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        f32x16 h2[2], lg[1];
+        f32x16 h2[2], lg[TO3];
         acc_load<2>(h2, s_b23, half, false);
         hidden_part<2, 0, 8, 0, 16>(h2, w2, h1[g]);
         __builtin_amdgcn_sched_barrier(0);
-        acc_load<1>(lg, s_b23 + H, half, false);
-        hidden_part<1, 0, 8, 0, 8>(lg, w3, h2);
+        acc_load<TO3>(lg, s_b23 + H, half, false);
+        if constexpr (TO3 == 1) {
+            hidden_part<1, 0, 8, 0, 8>(lg, w3, h2);
+        } else {
+            Frag<8> wa, wb;
+            wa.load(st + F3, 0, lane);
+            wb.load(st + F3, 8, lane);
+            hidden_part<2, 0, 4, 0, 8>(lg, wa, h2);
+            hidden_part<2, 4, 4, 4, 8>(lg, wb, h2);
+        }
         // Output 8q + 4h + c of the group's row j sits in register 4q + c of lane (j, h); the row's lane is (j, 0)
         // for G = 1 and (j, g) for G = 2: it keeps the four outputs of its own half and receives the other four
         // from the lane 32 away.
@@ -162,7 +175,7 @@ __device__ __forceinline__ int policy_rows(const float* __restrict__ st, const f
         for (int q = 0; q < NQ; q++)
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const float own = lg[0][4 * q + c];
+                const float own = lg[q >> 2][4 * (q & 3) + c];
                 const float recv = __shfl_xor(own, 32);
                 if (G == 1 || half == g) {
                     x[8 * q + c] = half ? recv : own;
@@ -172,6 +185,11 @@ __device__ __forceinline__ int policy_rows(const float* __restrict__ st, const f
         __builtin_amdgcn_sched_barrier(0);
     }
     if (!mine) return -1;
+    if constexpr (TO3 == 2) {
+#pragma unroll
+        for (int a = 0; a < 8 * NQ; a++) av[a] = a < A ? avail[myrow * A + a] : 1;
+        if (uniforms) u01 = uniforms[myrow];
+    }
     // actor_outs[avail == 0] = -1e10 ; softmax ; sample (ppo_agent.py:69-73)
     float mx = -3.0e38f;
 #pragma unroll

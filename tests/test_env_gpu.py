@@ -533,20 +533,87 @@ def test_rollout_mlp_expert_policy_equals_per_step_launches(monkeypatch, B, chun
 
 @pytest.mark.gpu
 def test_rollout_mlp_policy_unsupported_shape_is_an_error():
-    """40 nodes = 41 actions: outside what the in-kernel Actor is compiled for; the entry point says so (the runner
-    keeps the per-step launches there)."""
+    """80 nodes = 81 actions: outside what the in-kernel Actor is compiled for (<= 64 actions); the entry point says so
+    (the runner keeps the per-step launches there)."""
     th = _th()
     from marl_amd import _abi
-    g = load_golden("env40")
-    args = args_from_golden(g)
+    from tests.util import make_args
+    args = make_args(["--edge_node_num=80", "--task_size_max=6000", "--seed=3"])
     N = args.edge_node_num
     env = _make_env(args, 3, 0)
-    assert not env.info_geometry()["rollout_mlp_policy"]
+    geo = env.info_geometry()
+    assert not geo["rollout_mlp_policy"] and not geo["rollout_mlp_expert_policy"]
     params = tuple(th.zeros(*d, device=env.device) for d in [(64, 9 + N), (64,), (64, 64), (64,), (N + 1, 64), (N + 1,)])
     env.reset()
     with pytest.raises(_abi.EcError):
         env.rollout_mlp_policy(params, 2)
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,expert,greedy,geometry", [(21, False, False, None), (21, True, False, None), (9, False, True, None),
+                                                      (13, True, False, (1, 2, 0)), (13, False, False, (1, 1, 0))])
+def test_rollout_mlp_policy_40_nodes(monkeypatch, B, expert, greedy, geometry):
+    """The 40-node topology of BASELINE configs[4] (41 actions: two output tiles in the Actor's last layer) through the
+    looping kernel, plain and expert-guided, == the per-step launches (ec_policy_forward, ec_expert_policy, ec_step), bit
+    for bit, in chunks of 30 steps over two episodes; with and without RNG producer waves (the rows of a 40-lane main wave
+    beyond its first 32 go to a producer wave when there is one)."""
+    th = _th()
+    from marl_amd.utils import mlp_device
+    g = load_golden("env40")
+    args = args_from_golden(g)
+    N, T = args.edge_node_num, args.episode_limit
+    ref_env = _make_env(args, B, 2)
+    if geometry:
+        for key, v in zip(("MARL_AMD_EC_EPW", "MARL_AMD_EC_MW", "MARL_AMD_EC_PRODUCERS"), geometry):
+            monkeypatch.setenv(key, str(v))
+    env = _make_env(args, B, 2)
+    geo = env.info_geometry()
+    assert geo["rollout_mlp_policy"] and geo["rollout_mlp_expert_policy"]
+    if geometry:
+        assert (geo["envs_per_wave"], geo["main_waves"], geo["rng_producer_waves"] > 0) == geometry[:2] + (bool(geometry[2]),)
+    dev = env.device
+    gen = th.Generator().manual_seed(777)
+    dims = [(64, 9 + N), (64,), (64, 64), (64,), (N + 1, 64), (N + 1,)]
+    params = tuple((th.randn(*d, generator=gen) * (0.6 if len(d) == 2 else 0.2)).to(dev) for d in dims)
+    seen = set()
+    for ep in range(2):
+        for e in (ref_env, env):
+            e.reset()
+            e.observe()
+        t = 0
+        while t < T:
+            k = min(30, T - t)
+            u = None if greedy else th.rand(k, B * N, generator=gen).to(dev)
+            coin = th.rand(k, B, generator=gen).to(dev) if expert else None
+            ratios = th.linspace(0.9, 0.1, k).to(dev) if expert else None
+            keys = ("reward", "terminated", "counters", "completion_time", "obs", "avail", "actions") + (("expert_actions",) if expert else ())
+            ref = {key: [] for key in keys}
+            for i in range(k):
+                _, _, a = mlp_device.policy_forward(params, ref_env.obs, N, ref_env.avail, None if greedy else u[i],
+                                                    want_probs=False)
+                a = a.view(B, N)
+                run = a
+                if expert:
+                    ex = ref_env.expert_actions()
+                    run = th.where((coin[i] < ratios[i]).unsqueeze(-1), ex, a)
+                    ref["expert_actions"].append(ex.clone())
+                r, term, info = ref_env.step(run)
+                for key, val in (("reward", r), ("terminated", term), ("counters", info["counters"]),
+                                 ("completion_time", info["task_completion_time"]), ("obs", ref_env.obs),
+                                 ("avail", ref_env.avail), ("actions", a)):
+                    ref[key].append(val.clone())
+            hist = env.rollout_mlp_policy(params, k, uniforms=u, coin=coin, ratios=ratios)
+            for key in ref:
+                assert th.equal(th.stack(ref[key]), hist[key]), (ep, t, key)
+            seen.update(hist["actions"].unique().tolist())
+            t += k
+    assert len(seen) > 8 and max(seen) > 32   # actions of the second output tile were taken
+    assert np.array_equal(ref_env.debug_dump(B - 1), env.debug_dump(B - 1))
+    assert np.array_equal(ref_env.debug_rng_cursors(), env.debug_rng_cursors())
+    for e in (ref_env, env):
+        assert e.status() & ~32 == 0
+        e.close()
 
 
 def test_lockstep_env_wider_than_a_wave(oracle_lib):

@@ -503,23 +503,26 @@ def test_buffer_contents_three_writers_and_oracle(oracle_lib):
     orc.close()
 
 
-def test_gail_runner_n40_expert_in_lockstep_with_oracle(oracle_lib):
+@pytest.mark.parametrize("kernel_rollout", [0, 1])
+def test_gail_runner_n40_expert_in_lockstep_with_oracle(oracle_lib, kernel_rollout):
     """BASELINE configs[4] shape (edge_node_num=40, GAIL): GAILRunner + GAILAgent for two iterations on the scaled
     topology.  During expert guidance (ratio 1.0 below bc_guidance_steps, gail_agent.py:68-75) every env executes the
     expert's action; an oracle env batch is driven by the same actions in lock step and its expert
-    (oc_expert_policy = optimal_agent.py:102-120,166-375 restated) must agree with ec_expert_policy at every step, as
-    must observation, mask and reward."""
+    (oc_expert_policy = optimal_agent.py:102-120,166-375 restated) must agree with the device's at every step, as
+    must observation, mask and reward.  kernel_rollout=0: the per-step launches (ec_expert_policy), checked as they
+    happen; 1: the whole episode in one launch (ec_rollout_mlp_expert_policy), checked from its histories."""
     from marl_amd import _abi
     from marl_amd.agent_register import agent_register
     from marl_amd.runners.runner_register import runner_register
     from oracle.ec_oracle import OracleEnv
     B, N, T, base = 40, 40, 20, 2
     a = _imitation_args("gail", B, edge_node_num=N, n_agents=N, n_actions=N + 1, state_shape=9 * N, episode_limit=T,
-                        ec_env_id_base=base, ec_hop_hist_len=32)
+                        ec_env_id_base=base, ec_hop_hist_len=32, ec_kernel_rollout=kernel_rollout)
     th.manual_seed(9)
     agent = agent_register["gail"](a)
     assert agent._fused_ok() and agent._fg_actor is not None     # N + 1 = 41 actions: still the HIP policy / update path
     runner = runner_register["gail_runner"](a, agent)
+    assert runner._kernel_rollout_ok(True) == bool(kernel_rollout)
     orc = OracleEnv(_abi.config_from_args(a, hop_hist_len=32), runner.env.tables, B, env_id_base=base, n_threads=4)
     state = {"t": 0, "checked": 0}
     inner = agent.get_expert_actions
@@ -553,6 +556,22 @@ def test_gail_runner_n40_expert_in_lockstep_with_oracle(oracle_lib):
         assert it * B * T + B * T <= a.bc_guidance_steps        # still ratio 1.0
         assert np.isfinite(info["episode_return"]) and all(bool(th.isfinite(v)) for v in agent.last_losses.values())
         assert "discriminator_loss" in agent.last_losses        # >= 10 expert transitions: the discriminator trained
+        if kernel_rollout:
+            hist = {k: v.cpu().numpy() for k, v in runner._hist.items()}
+            obs0, avail0 = runner.env.obs.cpu().numpy(), runner.env.avail.cpu().numpy()   # still from before the first step
+            for t in range(T):
+                o, av = orc.observe()
+                assert np.array_equal(obs0 if t == 0 else hist["obs"][t - 1], o.astype(np.float32)), (it, t)
+                assert np.array_equal(avail0 if t == 0 else hist["avail"][t - 1], av), (it, t)
+                want = orc.expert_policy(av)
+                assert np.array_equal(hist["expert_actions"][t], want), (it, t)
+                out = orc.step(want)
+                assert out["bad"] == 0
+                assert np.array_equal(hist["reward"][t], out["reward"].astype(np.float32)), (it, t)
+                state["checked"] += 1
+            # the PPO buffer holds the AGENT's masked draws, not what the envs executed
+            _, avail_b, actions_b, _, _, _ = agent.buffer.sample()
+            assert bool((avail_b.gather(-1, actions_b) == 1).all())
     assert state["checked"] == 2 * T and len(agent.expert_transitions) == min(2 * T * B, a.max_expert_buffer_size)
     n = len(agent.expert_transitions)
     ea = agent.expert_transitions.actions[:n]

@@ -15,11 +15,12 @@ from marl_amd.envs.edge_computing.multihop.edge_computing_config import add_edge
 from marl_amd.runners.runner_register import runner_register  # noqa: E402
 
 envs = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+nodes = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 p = argparse.ArgumentParser(conflict_handler="resolve")
 p = agent_config_register["gail"](add_edge_computing_env_args(add_default_args(p)))
-ns = p.parse_args(["--task_size_max=6000"])
-ns.n_threads, ns.obs_shape, ns.n_agents, ns.n_actions = envs, 9, 10, 11
-ns.state_shape, ns.device = 90, "cuda"
+ns = p.parse_args(["--task_size_max=6000", "--edge_node_num=%d" % nodes])
+ns.n_threads, ns.obs_shape, ns.n_agents, ns.n_actions = envs, 9, nodes, nodes + 1
+ns.state_shape, ns.device = 9 * nodes, "cuda"
 ns.ec_graph_rollout = 1
 th.manual_seed(100)
 agent = agent_register["gail"](ns)
