@@ -157,7 +157,8 @@ int ec_rollout_random_policy(ec_handle h, int32_t n_steps, int32_t keep_history,
  *   counters [n_steps,B,4], completion_time [n_steps,B], next_obs [n_steps,B,N,9], next_avail [n_steps,B,N,N+1]:
  *   slice t = outputs of step t; actions, next_obs, next_avail are required, the others may be NULL.  hop_hist
  *   (cumulative) is copied once, after the last step.
- * Compiled for k <= 4 parallel execution slots, in-degree <= 8 and N+1 <= 32 actions; EC_EINVAL otherwise (callers
+ * Compiled for k <= 4 parallel execution slots and either in-degree <= 8 with N+1 <= 32 actions or in-degree <= 4 with
+ * N+1 <= 64 actions (the 40-node topology of BASELINE configs[4]); EC_EINVAL otherwise (callers
  * keep the per-step launches for those shapes). */
 int ec_rollout_mlp_policy(ec_handle h, int32_t n_steps, const float* w1, const float* b1, const float* w2, const float* b2,
                           const float* w3, const float* b3, const float* uniforms, const float* obs0,
