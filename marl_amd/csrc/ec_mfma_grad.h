@@ -13,11 +13,12 @@ namespace {
 constexpr int TSTR = 33;
 constexpr int TILE = 64 * TSTR;          // floats per tile
 
-// out[to] += frag * f(in): TI input tiles of 16 accumulator registers (k order kperm), one group of 32 rows
-template <int TO, int TI, typename F>
+// out[to] += frag * f(in): TI input tiles of 16 accumulator registers (k order kperm), one group of 32 rows.
+// KQ: live 4-register groups of the LAST input tile (the k-steps of the others multiply zeros and are skipped).
+template <int TO, int TI, int KQ = 4, typename F>
 __device__ __forceinline__ void chain(f32x16 (&out)[TO], const float* __restrict__ frag, const f32x16 (&in)[TI], int lane, F f) {
 #pragma unroll
-    for (int s4 = 0; s4 < 4 * TI; s4++) {
+    for (int s4 = 0; s4 < 4 * (TI - 1) + KQ; s4++) {
 #pragma unroll
         for (int to = 0; to < TO; to++) {
             const float4 a = *reinterpret_cast<const float4*>(frag + ((s4 * TO + to) * 64 + lane) * 4);

@@ -72,12 +72,15 @@ struct PpoArgs {
 // HEAD 0: actor (TO3 output tiles), HEAD 1: critic.  IN1T: tiles of the first layer's dense input (9 + n_agents).
 // BWD false: the forward-only passes (old log-probs, old values): the same forward arithmetic without the persistent
 // gradient accumulators, so that two blocks fit a CU instead of one.
-template <int HEAD, int TO3, int IN1T, bool BWD>
+// NQ (actor): 8-column groups of the last output tile that hold actions (A <= 32 (TO3 - 1) + 8 NQ); the head's per-action
+// arithmetic and the k-steps of d2 = W3^T d3 beyond them are compiled out (11 actions: half of the head).
+template <int HEAD, int TO3, int IN1T, bool BWD, int NQ = 4>
 __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
     extern __shared__ __align__(16) float lds[];
     const int nw = blockDim.x >> 6;
     const int N = p.n_agents, A = p.A, in1 = OBS + N;
     constexpr int T3 = HEAD == 0 ? TO3 : 1;
+#define LIVE3(t, r) ((t) < T3 - 1 || (r) < 4 * NQ)  // register r of logits tile t can hold an action
     float* s_f1 = lds;                          // W1 obs part: 8 steps x 2
     float* s_f2 = s_f1 + 8 * 2 * 64;            // W2: 32 x 2
     float* s_f2t = s_f2 + 32 * 2 * 64;          // W2^T: 32 x 2
@@ -264,6 +267,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             for (int t = 0; t < T3; t++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
+                    if (!LIVE3(t, r)) continue;
                     const int j = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
                     float x = z[t][r];
                     if (j < A) {
@@ -278,6 +282,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             for (int t = 0; t < T3; t++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
+                    if (!LIVE3(t, r)) continue;
                     const int j = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
                     const float e = j < A ? expf(z[t][r] - mx) : 0.0f;
                     z[t][r] = e;
@@ -291,6 +296,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             for (int t = 0; t < T3; t++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
+                    if (!LIVE3(t, r)) continue;
                     const int j = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
                     const float pj = z[t][r] * inv;
                     // Categorical(probs): log of the clamped probability, zero gradient outside the clamp range;
@@ -339,6 +345,10 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             for (int t = 0; t < T3; t++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
+                    if (!LIVE3(t, r)) {
+                        z[t][r] = 0.0f;
+                        continue;
+                    }
                     const int j = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
                     const float pj = z[t][r];
                     const float dz = c1 * ((j == act ? 1.0f : 0.0f) - pj) + (nll ? 0.0f : p.entropy_coef * pj * (gk[t][r] - gbar));
@@ -355,7 +365,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             PST(5);
             // d2 = (W3^T d3) .* [h2 > 0]
             acc_zero<2>(d2);
-            chain<2, T3>(d2, s_f3t, z, lane, [](int, int, float x) { return x; });
+            chain<2, T3, NQ>(d2, s_f3t, z, lane, [](int, int, float x) { return x; });
         } else {
             // ---- critic head: v = w3 . relu(h2) + b3 ; loss = ((v - target) * mask)^2 / denom (ppo_agent.py:124-125)
             float part = 0.0f;
@@ -526,6 +536,8 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
     }
 }
 
+#undef LIVE3
+
 // second launch of a backward pass: grads[i] += sum over blocks of their private sums, in a fixed order (8 segments of
 // the block range per entry, then the segments in order); loss likewise
 __global__ void __launch_bounds__(256) k_ppo_sum(const float* __restrict__ ws, int ws_stride, int n_blocks, int n_params,
@@ -580,8 +592,9 @@ size_t ppo_lds_bytes(int head, int TO3, int N, int A, int nw, bool bwd) {
     return sizeof(float) * (f + nw * per_wave);
 }
 
-template <int HEAD, int TO3, int IN1T>
+template <int HEAD, int TO3, int IN1T, int NQ = 4>
 int launch_ppo(const PpoArgs& a, hipStream_t stream) {
+    if (HEAD == 0 && NQ == 4 && a.A <= 32 * (TO3 - 1) + 16) return launch_ppo<HEAD, TO3, IN1T, HEAD == 0 ? 2 : 4>(a, stream);
     int nw = 4;
     const bool bwd = a.grads != nullptr;
     size_t lds = ppo_lds_bytes(HEAD, TO3, a.n_agents, a.A, nw, bwd);
@@ -593,7 +606,7 @@ int launch_ppo(const PpoArgs& a, hipStream_t stream) {
     const int64_t tiles = (a.R + 31) / 32;
     int64_t blocks = (tiles + nw - 1) / nw;
     if (a.grads) {
-        EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ppo<HEAD, TO3, IN1T, true>),
+        EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ppo<HEAD, TO3, IN1T, true, NQ>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (blocks > 256) blocks = 256;  // one block per CU: the row loop amortises weight staging and the final atomics
         // MARL_AMD_PPO_MIN_TILES (diagnostic): fewer, longer-running blocks.  Measured at DGAIL's 262 k-row minibatch
@@ -608,15 +621,15 @@ int launch_ppo(const PpoArgs& a, hipStream_t stream) {
         if (int rc = ppo_workspace(&b.ws)) return rc;
         b.ws_stride = PPO_WS_STRIDE;
         if (n_params + 1 > PPO_WS_STRIDE || blocks > PPO_WS_BLOCKS) b.ws = nullptr;
-        hipLaunchKernelGGL((k_ppo<HEAD, TO3, IN1T, true>), dim3((unsigned)blocks), dim3(64 * nw), lds, stream, b);
+        hipLaunchKernelGGL((k_ppo<HEAD, TO3, IN1T, true, NQ>), dim3((unsigned)blocks), dim3(64 * nw), lds, stream, b);
         if (b.ws)
             hipLaunchKernelGGL(k_ppo_sum, dim3((n_params + 1 + 31) / 32), dim3(256), 0, stream, b.ws, b.ws_stride, (int)blocks,
                                n_params, a.grads, a.loss);
     } else {
-        EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ppo<HEAD, TO3, IN1T, false>),
+        EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ppo<HEAD, TO3, IN1T, false, NQ>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (blocks > 512) blocks = 512;  // two blocks per CU: no transposition tiles in LDS, a third of the registers
-        hipLaunchKernelGGL((k_ppo<HEAD, TO3, IN1T, false>), dim3((unsigned)blocks), dim3(64 * nw), lds, stream, a);
+        hipLaunchKernelGGL((k_ppo<HEAD, TO3, IN1T, false, NQ>), dim3((unsigned)blocks), dim3(64 * nw), lds, stream, a);
     }
     EC_HIP(hipGetLastError());
     return EC_OK;
