@@ -67,14 +67,15 @@ __device__ __forceinline__ void put_tile(float* __restrict__ tile, const f32x16 
 }
 
 // acc[to][ti] += Td[out][row] (x) Ta[in][row] over the tile's 32 rows; dbias[to] += sum_rows Td[out][row] (lane's parity)
-template <int TO, int TI>
+// UNR = 16: straight-line code, for a call site whose surroundings are to be scheduled between the MFMAs
+template <int TO, int TI, int UNR = 4>
 __device__ __forceinline__ void wgrad(f32x16 (&acc)[TO][TI], float (&dbias)[TO], const float* __restrict__ Td,
                                       const float* __restrict__ Ta, int lane) {
 #ifdef ABL_NO_WGRAD
     return;
 #endif
     const int i = lane & 31, half = lane >> 5;
-#pragma unroll 4
+#pragma unroll UNR
     for (int s = 0; s < 16; s++) {
         const int row = 2 * s + half;
         float a[TO], b[TI];

@@ -200,6 +200,14 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
         f.m = f.ok ? (p.mask ? p.mask[f.trow] : 1.0f) : 0.0f;
         return f;
     };
+    // The first layer's weight-gradient MFMAs of a tile are issued inside the NEXT tile's head: they depend on nothing
+    // there, and the head is the one long stretch of vector arithmetic during which the matrix pipe would idle (a wave
+    // alone on its SIMD overlaps the two only where the instruction stream interleaves them).  The exchange tiles hold
+    // layer 1's operands until the next tile's first put; they start as zeros, and the last tile's product follows the loop.
+    if (BWD) {
+        for (int i = lane; i < 2 * TILE; i += 64) Td[i] = 0.0f;
+        wave_sync();
+    }
     const int64_t tile0 = (int64_t)blockIdx.x * nw + wave, tstride = (int64_t)gridDim.x * nw;
     int64_t idx_next = 0, idx_next2 = 0;
     Pre cur, nxt;
@@ -259,6 +267,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             acc_init<T3>(z, s_b3, half);
             chain<T3, 2>(z, s_f3, h2, lane, [](int, int, float x) { return relu(x); });
             PST(2);
+            if (BWD) wgrad<2, IN1T, 16>(gW1, gb1, Td, Ta, lane);  // the previous tile's dW1 (see above)
             // ---- head: masked softmax, Categorical log-prob / entropy, clipped surrogate (ppo_agent.py:76-83,135-141)
             const int act = cur.act;
             const bool clampp = !(p.flags & EC_PPO_LOGITS);
@@ -368,6 +377,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             chain<2, T3, NQ>(d2, s_f3t, z, lane, [](int, int, float x) { return x; });
         } else {
             // ---- critic head: v = w3 . relu(h2) + b3 ; loss = ((v - target) * mask)^2 / denom (ppo_agent.py:124-125)
+            if (BWD) wgrad<2, IN1T, 16>(gW1, gb1, Td, Ta, lane);  // the previous tile's dW1 (see above)
             float part = 0.0f;
 #pragma unroll
             for (int t = 0; t < 2; t++)
@@ -444,9 +454,8 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             Ta[in * TSTR + jrow] = in < OBS ? s_obs[jrow * OBS + in] : ((ok && N > 0 && in - OBS == agent) ? 1.0f : 0.0f);
         wave_sync();
         PST(4);
-        wgrad<2, IN1T>(gW1, gb1, Td, Ta, lane);
-        PST(5);
     }
+    if (BWD) wgrad<2, IN1T>(gW1, gb1, Td, Ta, lane);
 #ifdef ABL_PPO_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0 && BWD && n_tiles > 10000)
         printf("k_ppo<head %d> cycles per section, wave 0 of block 0: load %llu | fwd L1+L2 %llu | L3 %llu | head %llu | put %llu | "
