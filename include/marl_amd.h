@@ -409,6 +409,20 @@ int ec_expert_append_episode(const float* coin, const float* ratios, const int64
                              int64_t capacity, float* ring_obs, int64_t* ring_actions, int64_t* written, int64_t* n_expert,
                              void* workspace, void* stream);
 
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.Adam.step() (no weight decay, no amsgrad) for
+ * up to 4 small networks of up to 8 fp32 tensors each in one launch, one block per network: the end of every optimiser
+ * step of the learners (dgail_agent.py:319-325, ppo_agent.py:128-141, gail_agent.py:222-231), ~40 torch launches otherwise.
+ *   n_tensors [n_nets];  params / grads / exp_avg / exp_avg_sq / steps: device pointers, the networks' tensors one after
+ *   the other (sum n_tensors entries), numel likewise;  steps: the optimiser's device step counters (capturable Adam;
+ *   incremented by the launch), or NULL entries for a network whose step count the host keeps: step_host [n_nets] then holds
+ *   the NEW step count;  lr, beta1, beta2, eps, max_norm [n_nets] (host doubles, rounded to fp32 where torch rounds
+ *   them: 1 - beta in double first; max_norm <= 0: no clipping).
+ * grads are left scaled by the clip coefficient, as clip_grad_norm_ leaves them. */
+int ec_adam_clip_step(int32_t n_nets, const int32_t* n_tensors, float* const* params, float* const* grads,
+                      float* const* exp_avg, float* const* exp_avg_sq, float* const* steps, const int64_t* numel,
+                      const double* step_host, const double* lr, const double* beta1, const double* beta2,
+                      const double* eps, const double* max_norm, void* stream);
+
 /* The tail of a GAIL-discriminator layer -- BatchNorm1d in training mode, ReLU, Dropout(p) (gail_network.py:97-125:
  * fc -> bn -> activation -> dropout) -- over x [rows, C] fp32, C a multiple of 4 with C/4 dividing 256, with the batch
  * statistics folded into scale = invstd * weight and shift = bias - mean * scale by the caller:

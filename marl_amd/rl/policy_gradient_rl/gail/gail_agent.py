@@ -20,7 +20,7 @@ from torch.optim import Adam
 from marl_amd.buffer.expert_transitions import ExpertTransitions
 from marl_amd.buffer.ppo_expert_buffer import PPOExpertBuffer
 from marl_amd.rl.policy_gradient_rl.gail.gail_network import Actor, Critic, Discriminator
-from marl_amd.utils import mlp_device, ppo_device
+from marl_amd.utils import mlp_device, optim_device, ppo_device
 from marl_amd.utils.action_selectors import greedy_selector, soft_selector
 from marl_amd.utils.advantage_utils import get_gae
 from marl_amd.utils.dist_utils import (all_reduce_grads_, all_reduce_sum_, broadcast_params_, global_mean_std,
@@ -177,9 +177,7 @@ class GAILAgent:
             ppo_device.critic_pass(self.critic, obs, masks, N, target=targets, inv_denom=inv_denom,
                                    grads=self._fg_critic.flat, loss=losses[0:1])
             all_reduce_sum_(self._fg_critic.flat)
-            if a.use_grad_clip:
-                th.nn.utils.clip_grad_norm_(self.critic.parameters(), a.grad_norm_clip)
-            self.critic_optimizer.step()
+            self._clip_and_step(self.critic, self.critic_optimizer)
 
             self._fg_actor.zero_()
             ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, old_logp=old_logp, adv=advantages,
@@ -192,9 +190,7 @@ class GAILAgent:
                 ppo_device.actor_pass(self.actor, e_obs, None, e_act, None, N, grads=self._fg_actor.flat, logits=True,
                                       nll=True, inv_denom=self.bc_loss_weight / (e_act.numel() * world_size()))
             all_reduce_sum_(self._fg_actor.flat)
-            if a.use_grad_clip:
-                th.nn.utils.clip_grad_norm_(self.actor.parameters(), a.grad_norm_clip)
-            self.actor_optimizer.step()
+            self._clip_and_step(self.actor, self.actor_optimizer)
         all_reduce_sum_(losses)
         self.update_count += 1
         self.last_losses.update({"critic_loss": losses[0].clone(), "actor_loss": losses[1].clone()})
@@ -254,6 +250,15 @@ class GAILAgent:
         if self.update_count % 100 == 0:
             print("Update %d: BC weight = %.4f, expert data size = %d" % (self.update_count, self.bc_loss_weight,
                                                                          len(self.expert_transitions)))
+
+    def _clip_and_step(self, net, optimizer):
+        """clip_grad_norm_ + Adam.step() (gail_agent.py:222-231): one launch (ec_adam_clip_step), or torch's ~20"""
+        a = self.args
+        if optim_device.clip_adam_step([optimizer], a.grad_norm_clip if a.use_grad_clip else None):
+            return
+        if a.use_grad_clip:
+            th.nn.utils.clip_grad_norm_(net.parameters(), a.grad_norm_clip)
+        optimizer.step()
 
     def update_performance_monitoring(self, success_rate):
         """gail_agent.py:233-236"""
