@@ -433,6 +433,10 @@ int ec_adam_clip_step(int32_t n_nets, const int32_t* n_tensors, float* const* pa
  *             caller from the sums and the statistics)
  * keep: `mask` [rows, C] u8 when given, else a counter-based Bernoulli(1 - p) draw from (seed, element index) that the
  * backward recomputes instead of reading.  Replaces F.batch_norm / relu / F.dropout and their autograd backward. */
+/* The batch statistics of the same layer in one streaming pass: partials [n_partials][2][C] <- per-block sums over rows of
+ * (x - x[0]) and (x - x[0])^2 per column (row 0 as the pivot); the caller adds the partials up (in float64) and takes
+ * mean = x[0] + S1/n, biased var = S2/n - (S1/n)^2.  Replaces torch.var_mean(x, dim=0). */
+int ec_bn_col_stats(const float* x, int64_t rows, int32_t C, int32_t n_partials, float* partials, void* stream);
 int ec_bn_relu_dropout_fwd(const float* x, const float* scale, const float* shift, const uint8_t* mask, uint64_t seed, float p,
                            int64_t rows, int32_t C, float* out, void* stream);
 int ec_bn_relu_dropout_bwd_sums(const float* dout, const float* x, const float* scale, const float* shift, const uint8_t* mask,

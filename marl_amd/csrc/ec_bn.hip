@@ -137,6 +137,51 @@ __global__ void __launch_bounds__(256) k_bn_tail_sums(BnArgs p) {
     }
 }
 
+// Batch statistics in one pass: partials[blk][0][col] = sum over the block's rows of (x - k), [blk][1][col] of (x - k)^2,
+// with the pivot k = x[0][col] (a sample of the column, so the sums stay of the size of the spread and
+// var = S2/n - (S1/n)^2 does not cancel; the caller adds the partials up in float64).  torch's var_mean on a
+// [rows, C] column reduction runs at a third of the HBM rate; this is the same thread mapping as k_bn_tail_sums.
+__global__ void __launch_bounds__(256) k_bn_col_stats(BnArgs p) {
+    __shared__ float s_red[2][4][256];
+    const int q4 = p.C >> 2;
+    const int lanes = 256 / q4;
+    const int q = threadIdx.x % q4, rl = threadIdx.x / q4;
+    const int col = q * 4;
+    const int64_t per = (p.rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < p.rows ? r0 + per : p.rows;
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (rl < lanes) {
+        const float4 k = *reinterpret_cast<const float4*>(p.x + col);
+        const float kv[4] = {k.x, k.y, k.z, k.w};
+        for (int64_t r = r0 + rl; r < r1; r += lanes) {
+            const float4 x = *reinterpret_cast<const float4*>(p.x + r * p.C + col);
+            const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float d = xv[j] - kv[j];
+                s1[j] += d;
+                s2[j] = fmaf(d, d, s2[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        s_red[0][j][threadIdx.x] = s1[j];
+        s_red[1][j][threadIdx.x] = s2[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < q4) {
+#pragma unroll
+        for (int w = 0; w < 2; w++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float t = 0.0f;
+                for (int l = 0; l < lanes; l++) t += s_red[w][j][l * q4 + q];
+                p.out[((size_t)blockIdx.x * 2 + w) * p.C + col + j] = t;
+            }
+    }
+}
+
 int bn_check(const char* what, const BnArgs& a, float p) {
     if (!a.x || !a.scale || !a.shift || !a.out) return ec::fail(EC_EINVAL, "%s: null pointer", what);
     if (a.rows < 0 || a.C < 4 || a.C > 256 || (a.C & 3) || (256 % (a.C >> 2)))
@@ -166,6 +211,15 @@ int ec_bn_relu_dropout_fwd(const float* x, const float* scale, const float* shif
     const BnArgs a = bn_args(x, nullptr, scale, shift, mask, seed, p, rows, C, nullptr, nullptr, nullptr, out);
     if (int rc = bn_check("ec_bn_relu_dropout_fwd", a, p)) return rc;
     hipLaunchKernelGGL(k_bn_tail<0>, dim3(bn_grid(rows * (C >> 2))), dim3(256), 0, (hipStream_t)stream, a);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+int ec_bn_col_stats(const float* x, int64_t rows, int32_t C, int32_t n_partials, float* partials, void* stream) {
+    const BnArgs a = bn_args(x, nullptr, x, x, nullptr, 0, 0.0f, rows, C, nullptr, nullptr, nullptr, partials);
+    if (int rc = bn_check("ec_bn_col_stats", a, 0.0f)) return rc;
+    if (rows < 1 || n_partials < 1) return ec::fail(EC_EINVAL, "ec_bn_col_stats: rows %lld, n_partials %d", (long long)rows, n_partials);
+    hipLaunchKernelGGL(k_bn_col_stats, dim3(n_partials), dim3(256), 0, (hipStream_t)stream, a);
     EC_HIP(hipGetLastError());
     return EC_OK;
 }

@@ -157,7 +157,18 @@ class _BnReluDropHipFn(th.autograd.Function):
 
         from marl_amd import _abi
         x = x.contiguous()
-        var, mean = th.var_mean(x, dim=0, unbiased=False)
+        rows, Cc = x.shape
+        stream = C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)
+        # batch statistics: one streaming pass (ec_bn_col_stats; torch.var_mean's column reduction runs at a third of
+        # the HBM rate), per-block partial sums about the pivot row x[0], added up in float64
+        n_part = int(min(_BnReluDropHipFn.N_PARTIALS, max(1, rows // 64)))
+        partials = th.empty(n_part, 2, Cc, dtype=th.float32, device=x.device)
+        with th.cuda.device(x.device):
+            _abi.check(_abi.lib().ec_bn_col_stats(C.c_void_p(x.data_ptr()), rows, Cc, n_part,
+                                                  C.c_void_p(partials.data_ptr()), stream), "ec_bn_col_stats")
+        s = partials.double().sum(0) / rows
+        mean = (x[0].double() + s[0]).float()
+        var = (s[1] - s[0] * s[0]).clamp_(min=0.0).float()
         invstd = th.rsqrt(var + eps)
         scale = (invstd * weight).contiguous()
         shift = (bias - mean * scale).contiguous()
@@ -166,8 +177,6 @@ class _BnReluDropHipFn(th.autograd.Function):
             mask = mask.to(device=x.device, dtype=th.uint8).contiguous()
         seed = int(th.empty((), dtype=th.int64).random_())   # torch's CPU generator: follows th.manual_seed, no device sync
         out = th.empty_like(x)
-        rows, Cc = x.shape
-        stream = C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)
         vp, head = _BnReluDropHipFn._args(x, scale, shift, mask, seed, p)
         with th.cuda.device(x.device):
             _abi.check(_abi.lib().ec_bn_relu_dropout_fwd(*head, rows, Cc, vp(out), stream), "ec_bn_relu_dropout_fwd")

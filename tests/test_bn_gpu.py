@@ -78,3 +78,26 @@ def test_hip_layer_tail_own_mask():
     cols, rws = kept.float().mean(0), kept.float().mean(1)          # no column or row pattern
     assert float(cols.min()) > 0.69 and float(cols.max()) < 0.71
     assert float(rws.min()) > 0.45 and float(rws.max()) < 0.92
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C,offset", [(2, 32, 0.0), (1000, 128, 0.0), (100003, 64, 50.0), (1 << 21, 32, -300.0), (65, 4, 1e4)])
+def test_col_stats_matches_float64(rows, C, offset):
+    """ec_bn_col_stats (the one-pass batch statistics of the layer tail): mean and biased variance per column against
+    float64, also for columns whose mean is hundreds of standard deviations from zero (the sums are taken about the
+    pivot row, so E[x^2] - mean^2 does not cancel)."""
+    import ctypes as C_
+    import torch as th
+    from marl_amd import _abi
+    gen = th.Generator().manual_seed(rows + C)
+    x = (th.randn(rows, C, generator=gen) * th.linspace(0.1, 3.0, C) + offset * th.linspace(-1, 1, C)).cuda()
+    n_part = min(1024, max(1, rows // 64))
+    partials = th.full((n_part, 2, C), float("nan"), device="cuda")
+    _abi.check(_abi.lib().ec_bn_col_stats(C_.c_void_p(x.data_ptr()), rows, C, n_part, C_.c_void_p(partials.data_ptr()),
+                                          C_.c_void_p(th.cuda.current_stream().cuda_stream)), "ec_bn_col_stats")
+    s = partials.double().sum(0) / rows
+    mean = x[0].double() + s[0]
+    var = s[1] - s[0] * s[0]
+    want_var, want_mean = th.var_mean(x.double(), dim=0, unbiased=False)
+    assert th.allclose(mean, want_mean, rtol=1e-6, atol=1e-6)
+    assert th.allclose(var, want_var, rtol=2e-5, atol=1e-9)
