@@ -87,10 +87,15 @@ class DGAILAgent:
         self._fg_policy = self._fg_value = self._fg_gail = self._fg_bc = None
         self._noted_torch_disc = False
         if self._fused_ok() and not getattr(args, "ec_torch_update", False):
-            self._fg_policy = ppo_device.FlatGrads(self.policy)
-            self._fg_value = ppo_device.FlatGrads(self.value)
+            # one buffer for what a minibatch step clears: [policy grads | value grads | BC grads | 2 loss words]
+            n_p = sum(p.numel() for p in self.policy.parameters())
+            n_v = sum(p.numel() for p in self.value.parameters())
+            self._fg_step = th.zeros(2 * n_p + n_v + 2, dtype=th.float32, device=self.device)
+            self._fg_policy = ppo_device.FlatGrads(self.policy, self._fg_step[:n_p])
+            self._fg_value = ppo_device.FlatGrads(self.value, self._fg_step[n_p:n_p + n_v])
+            self._fg_bc = self._fg_step[n_p + n_v:2 * n_p + n_v]  # the BC term's gradient before its weight
+            self._fg_losses = self._fg_step[2 * n_p + n_v:]
             self._fg_gail = ppo_device.FlatGrads(self.gail_discriminator)
-            self._fg_bc = th.zeros_like(self._fg_policy.flat)  # the BC term's gradient before its weight
         elif self.device.type == "cuda":
             print("DGAILAgent: hidden_dim=%s / obs_shape=%s / ec_torch_update: the policy/value update runs on torch "
                   "autograd, not on the fused HIP kernels" % (args.hidden_dim, self.obs_shape))
@@ -415,8 +420,11 @@ class DGAILAgent:
                     graph["graph"].replay()
                 else:
                     self._fused_step(tables, idx.contiguous(), bc, bc_w, totals)
-        totals = (totals / (a.ppo_epochs * n_mb)).tolist()
-        return {"policy_loss": totals[0], "value_loss": totals[1], "entropy": totals[2]}
+        ws = world_size()
+        k_loss, v_loss, ent_mean = (totals / (a.ppo_epochs * n_mb)).tolist()
+        # the kernel's actor loss is policy_loss - c_H * entropy; the reference reports the three terms separately
+        return {"policy_loss": k_loss * ws + a.entropy_coef * ent_mean, "value_loss": v_loss * ws / a.value_loss_coef,
+                "entropy": ent_mean}
 
     def _fused_step(self, tables, idx, bc, bc_w, totals):
         """dgail_agent.py:283-325 for the rows `idx`: loss = policy - c_H * H + c_V * value + w_bc * BC, clipped Adam
@@ -424,9 +432,8 @@ class DGAILAgent:
         a = self.args
         obs_f, act_f, logp_old, adv_f, ret_f = tables
         n = idx.shape[0]
-        losses = th.zeros(2, device=self.device)
-        self._fg_policy.zero_()
-        self._fg_value.zero_()
+        self._fg_step.zero_()  # both networks' gradients, the BC gradient and the two loss words in one fill
+        losses = self._fg_losses
         ws = world_size()
         # (under data parallelism every rank's share enters with weight 1 / world: the summed gradient is the mean)
         # The kernels fetch the minibatch rows through `row_index` themselves (a 36-byte row per lane; gathering the five
@@ -439,7 +446,6 @@ class DGAILAgent:
                                grads=self._fg_value.flat, loss=losses[1:2], row_index=idx)
         # BC term (dgail_agent.py:255-262, 309): the same kernel with the cross-entropy objective on the expert rows,
         # into a buffer of its own so that its weight stays a device scalar (the captured step outlives one value of it)
-        self._fg_bc.zero_()
         ppo_device.actor_pass(self.policy, bc[0], None, bc[1], None, self.n_agents, inv_denom=1.0 / (bc[1].numel() * ws),
                               grads=self._fg_bc, logits=True, nll=True)
         self._fg_policy.flat.addcmul_(self._fg_bc, bc_w)
@@ -451,9 +457,10 @@ class DGAILAgent:
             th.nn.utils.clip_grad_norm_(self.value.parameters(), a.grad_norm_clip)
             self.policy_optimizer.step()
             self.value_optimizer.step()
-        ent_mean = ent.mean()
-        # the kernel's actor loss is policy_loss - c_H * entropy; the reference reports the three terms separately
-        totals += th.stack([losses[0] * ws + a.entropy_coef * ent_mean, losses[1] * ws / a.value_loss_coef, ent_mean])
+        # raw sums only (two launches): [actor-kernel loss, weighted value loss, mean entropy]; _update_policy_fused turns
+        # them into the three terms the reference reports
+        totals[0:2].add_(losses)
+        totals[2:3].add_(ent.mean())
 
     def _fused_graph(self, tables, mb, bc_w):
         """Static copies of the iteration's per-row tables and one captured _fused_step over them (see

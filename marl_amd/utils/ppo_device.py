@@ -12,10 +12,14 @@ from marl_amd.utils.mlp_device import OBS_DIM, _f32, _p, _stream, linear_params
 
 
 class FlatGrads:
-    def __init__(self, module):
+    def __init__(self, module, storage=None):
+        """storage: optional zeroed fp32 tensor of exactly the module's parameter count to use as the flat buffer (a slice
+        of a larger one, so that several networks' gradients are cleared by one fill)"""
         self.params = [p for p in module.parameters()]
         n = sum(p.numel() for p in self.params)
-        self.flat = th.zeros(n, dtype=th.float32, device=self.params[0].device)
+        if storage is not None and (storage.numel() != n or storage.dtype != th.float32 or not storage.is_contiguous()):
+            raise ValueError("FlatGrads storage must be a contiguous float32 tensor of %d elements" % n)
+        self.flat = storage if storage is not None else th.zeros(n, dtype=th.float32, device=self.params[0].device)
         self.bind()
 
     def bind(self):
