@@ -269,6 +269,18 @@ int ec_diffusion_grad(const float* w1, int32_t ld1, const float* bias_t, const f
                       const float* noise, const float* coef, int64_t rows, int32_t n_actions, int32_t hidden,
                       float r1_lambda, float* loss, float* grads, void* stream);
 
+/* ec_diffusion_grad with the per-row coefficient taken in the kernel: the derivative of the discriminator objective of
+ * dgail_agent.py:209-221 -- D_phi = exp(-lp) / (exp(-lp) + exp(-ln) + 1e-8), F.binary_cross_entropy(D_phi, label), mean over
+ * rows -- with respect to this call's per-row loss, from that loss and the other condition's (`other_loss` [rows]).
+ *   side 0: this call is lp (condition 1), 1: ln (condition 0);  label: 1 expert rows, 0 agent rows;  scale: 1 / rows.
+ * loss (optional) <- this call's per-row loss.  Lets a data set's update run as forward(c=1), forward+backward(c=0),
+ * forward+backward(c=1): three launches instead of four. */
+int ec_diffusion_grad_bce(const float* w1, int32_t ld1, const float* bias_t, const float* w2, const float* b2,
+                          const float* w3, const float* b3, const float* w3sum, const float* obs, const int64_t* actions,
+                          const uint8_t* t, const float* noise, const float* other_loss, int32_t side, int32_t label,
+                          float scale, int64_t rows, int32_t n_actions, int32_t hidden, float r1_lambda, float* loss,
+                          float* grads, void* stream);
+
 /* --- rollout bookkeeping ----------------------------------------------------------------------------------------
  * One launch per env step instead of ~20 torch launches: replaces EpisodeBuffer.insert (buffer/episode_buffer.py:21-28)
  * with the team-reward broadcast and mask = 1 - terminated of parallel_episode_runner.py:101-102, and the running

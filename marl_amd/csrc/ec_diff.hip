@@ -38,6 +38,12 @@ struct DiffArgs {
     int A;
     float lambda;
     float* loss_out;  // [R] or NULL
+    // ec_diffusion_grad_bce: the coefficient is the derivative of D_phi's BCE (dgail_agent.py:209-221) with respect to this
+    // call's per-row loss L, computed in the kernel from L and the OTHER condition's loss of the same row:
+    //   p = exp(-lp) / (exp(-lp) + exp(-ln) + 1e-8);  BCE(p, label) mean over rows;  side 0: this call is lp, 1: ln
+    const float* other;  // [R] or NULL (coef is used)
+    int side, label;
+    float bce_scale;     // 1 / rows (x the data-parallel weight)
     float* grads;     // [dW1x H*SA | dbias(t=0)+dbias(t=1) H | dbias(t=1) H | dW2 H*H | db2 H | dW3 SA*H | db3 SA | dw3sum H]
 };
 
@@ -105,7 +111,8 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
         int act = ok ? (int)p.actions[row] : 0;
         act = act < 0 ? 0 : (act >= A ? A - 1 : act);  // (obs | one-hot action), dgail_agent.py:199-201
         const int tr = (ok && p.t[row]) ? 1 : 0;
-        const float cf = (BWD && ok) ? p.coef[row] : 0.0f;
+        float cf = (BWD && ok && p.coef) ? p.coef[row] : 0.0f;
+        const float other = (BWD && ok && p.other) ? p.other[row] : 0.0f;
         // the wave's x_t and noise tiles [32][SAp] (zero rows beyond R)
         wave_sync();
         for (int i0 = 0; i0 < 32 * SA; i0 += 64) {
@@ -156,7 +163,6 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
         acc_init<TX>(e, s_b3, half);
         chain<TX, 2>(e, s_f3, h2, lane, relu_f);
         float mse = 0.0f;
-        const float c3 = cf * 2.0f / (float)SA;
 #pragma unroll
         for (int t = 0; t < TX; t++)
 #pragma unroll
@@ -164,7 +170,7 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
                 const int k = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
                 const float dlt = k < SA ? e[t][r] - s_noise[jrow * SAp + k] : 0.0f;
                 mse = fmaf(dlt, dlt, mse);
-                e[t][r] = c3 * dlt;
+                e[t][r] = dlt;  // (scaled by the row's coefficient below, once the row's loss is known)
             }
         mse = (mse + __shfl_xor(mse, 32)) / (float)SA;  // F.mse_loss(reduction="none").mean(dim=1), :97
 
@@ -181,8 +187,23 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) r1 = fmaf(g[t][r], g[t][r], r1);  // entries >= SA are exact zeros
         r1 += __shfl_xor(r1, 32);
-        if (ok && half == 0 && p.loss_out) p.loss_out[row] = mse + r1 * p.lambda;
+        const float L = mse + r1 * p.lambda;
+        if (ok && half == 0 && p.loss_out) p.loss_out[row] = L;
         if (!BWD) continue;
+        if (p.other) {
+            const float lp = p.side == 0 ? L : other, ln = p.side == 0 ? other : L;
+            const float ea = expf(-lp), eb = expf(-ln), s = ea + eb + 1e-8f, pr = ea / s;
+            // F.binary_cross_entropy backward: (p - y) / max((1 - p) p, 1e-12) / rows;  d p / d lp = -p (1 - p),
+            // d p / d ln = p exp(-ln) / s
+            const float dLdp = (pr - (float)p.label) / fmaxf((1.0f - pr) * pr, 1e-12f);
+            const float dpdl = p.side == 0 ? -pr * (1.0f - pr) : pr * eb / s;
+            cf = ok ? dLdp * dpdl * p.bce_scale : 0.0f;
+        }
+        const float c3 = cf * 2.0f / (float)SA;
+#pragma unroll
+        for (int t = 0; t < TX; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) e[t][r] *= c3;
 
         float nob[2] = {0.0f, 0.0f};  // bias sums of the products that have no bias
         // (1) dW3 += d3 (x) relu(a2);  d2 = m2 .* W3^T d3
@@ -347,27 +368,48 @@ int launch_diff(const DiffArgs& a, hipStream_t stream) {
 
 extern "C" {
 
+static int diffusion_grad_impl(const char* what, const float* w1, int32_t ld1, const float* bias_t, const float* w2,
+                               const float* b2, const float* w3, const float* b3, const float* w3sum, const float* obs,
+                               const int64_t* actions, const uint8_t* t, const float* noise, const float* coef,
+                               const float* other, int side, int label, float bce_scale, int64_t rows, int32_t n_actions,
+                               int32_t hidden, float r1_lambda, float* loss, float* grads, void* stream) {
+    if (rows == 0) return EC_OK;
+    if (rows < 0) return ec::fail(EC_EINVAL, "%s: rows < 0", what);
+    if (!w1 || !bias_t || !w2 || !b2 || !w3 || !b3 || !w3sum || !obs || !actions || !t || !noise)
+        return ec::fail(EC_EINVAL, "%s: null pointer", what);
+    if (hidden != H) return ec::fail(EC_EINVAL, "%s: hidden_dim %d unsupported (this build: %d)", what, hidden, H);
+    const int SA = OBS + n_actions;
+    if (n_actions < 1 || SA > 64) return ec::fail(EC_EINVAL, "%s: obs+actions = %d exceeds 64", what, SA);
+    if (ld1 < SA) return ec::fail(EC_EINVAL, "%s: ld1 %d < obs+actions %d", what, ld1, SA);
+    if (grads && !coef && !other) return ec::fail(EC_EINVAL, "%s: grads without a coefficient", what);
+    if (!grads && !loss) return ec::fail(EC_EINVAL, "%s: neither loss nor grads requested", what);
+    // the backward borrows input column SA of the first layer's gradient tile for the per-t bias sums
+    if (grads && (SA == 32 || SA == 64)) return ec::fail(EC_EINVAL, "%s: obs+actions = %d leaves no spare input column", what, SA);
+    DiffArgs a{w1, ld1, bias_t, w2, b2, w3, b3, w3sum, obs, actions, t, noise, coef, rows, n_actions, r1_lambda, loss,
+               other, side, label, bce_scale, grads};
+    const int TX = SA <= 32 ? 1 : 2;
+    if (grads) return TX == 1 ? launch_diff<1, true>(a, (hipStream_t)stream) : launch_diff<2, true>(a, (hipStream_t)stream);
+    return TX == 1 ? launch_diff<1, false>(a, (hipStream_t)stream) : launch_diff<2, false>(a, (hipStream_t)stream);
+}
+
 int ec_diffusion_grad(const float* w1, int32_t ld1, const float* bias_t, const float* w2, const float* b2, const float* w3,
                       const float* b3, const float* w3sum, const float* obs, const int64_t* actions, const uint8_t* t,
                       const float* noise, const float* coef, int64_t rows, int32_t n_actions, int32_t hidden,
                       float r1_lambda, float* loss, float* grads, void* stream) {
-    if (rows == 0) return EC_OK;
-    if (rows < 0) return ec::fail(EC_EINVAL, "ec_diffusion_grad: rows < 0");
-    if (!w1 || !bias_t || !w2 || !b2 || !w3 || !b3 || !w3sum || !obs || !actions || !t || !noise)
-        return ec::fail(EC_EINVAL, "ec_diffusion_grad: null pointer");
-    if (hidden != H) return ec::fail(EC_EINVAL, "ec_diffusion_grad: hidden_dim %d unsupported (this build: %d)", hidden, H);
-    const int SA = OBS + n_actions;
-    if (n_actions < 1 || SA > 64) return ec::fail(EC_EINVAL, "ec_diffusion_grad: obs+actions = %d exceeds 64", SA);
-    if (ld1 < SA) return ec::fail(EC_EINVAL, "ec_diffusion_grad: ld1 %d < obs+actions %d", ld1, SA);
-    if (grads && !coef) return ec::fail(EC_EINVAL, "ec_diffusion_grad: grads without coef");
-    if (!grads && !loss) return ec::fail(EC_EINVAL, "ec_diffusion_grad: neither loss nor grads requested");
-    // the backward borrows input column SA of the first layer's gradient tile for the per-t bias sums
-    if (grads && (SA == 32 || SA == 64))
-        return ec::fail(EC_EINVAL, "ec_diffusion_grad: obs+actions = %d leaves no spare input column", SA);
-    DiffArgs a{w1, ld1, bias_t, w2, b2, w3, b3, w3sum, obs, actions, t, noise, coef, rows, n_actions, r1_lambda, loss, grads};
-    const int TX = SA <= 32 ? 1 : 2;
-    if (grads) return TX == 1 ? launch_diff<1, true>(a, (hipStream_t)stream) : launch_diff<2, true>(a, (hipStream_t)stream);
-    return TX == 1 ? launch_diff<1, false>(a, (hipStream_t)stream) : launch_diff<2, false>(a, (hipStream_t)stream);
+    return diffusion_grad_impl("ec_diffusion_grad", w1, ld1, bias_t, w2, b2, w3, b3, w3sum, obs, actions, t, noise, coef, nullptr,
+                               0, 0, 0.0f, rows, n_actions, hidden, r1_lambda, loss, grads, stream);
+}
+
+int ec_diffusion_grad_bce(const float* w1, int32_t ld1, const float* bias_t, const float* w2, const float* b2,
+                          const float* w3, const float* b3, const float* w3sum, const float* obs, const int64_t* actions,
+                          const uint8_t* t, const float* noise, const float* other_loss, int32_t side, int32_t label,
+                          float scale, int64_t rows, int32_t n_actions, int32_t hidden, float r1_lambda, float* loss,
+                          float* grads, void* stream) {
+    if (!other_loss || !grads) return ec::fail(EC_EINVAL, "ec_diffusion_grad_bce: other_loss and grads are required");
+    if ((side != 0 && side != 1) || (label != 0 && label != 1))
+        return ec::fail(EC_EINVAL, "ec_diffusion_grad_bce: side %d / label %d must be 0 or 1", side, label);
+    return diffusion_grad_impl("ec_diffusion_grad_bce", w1, ld1, bias_t, w2, b2, w3, b3, w3sum, obs, actions, t, noise, nullptr,
+                               other_loss, side, label, scale, rows, n_actions, hidden, r1_lambda, loss, grads, stream);
 }
 
 }  // extern "C"

@@ -207,26 +207,28 @@ class DGAILAgent:
         act_f = actions.reshape(-1)
         rows = obs_f.shape[0]
         exp_obs, exp_act = self.expert_transitions.sample_rows(rows)
-        calls, losses = [], []
+        calls = []
         for o, a_ in ((exp_obs, exp_act), (obs_f, act_f)):
             for c in (1, 0):
                 t, noise = self.rng.diffusion_draws(rows, self.state_action_dim)
-                call = mlp_device.DiffusionLossCall(d, c, o, a_, self.n_actions, t, noise)
-                calls.append(call)
-                losses.append(call.loss(d.R1_LAMBDA).requires_grad_(True))
-
-        def d_phi(lp, ln):
-            return th.exp(-lp) / (th.exp(-lp) + th.exp(-ln) + 1e-8)
-        prob_expert, prob_agent = d_phi(losses[0], losses[1]), d_phi(losses[2], losses[3])
-        loss = (F.binary_cross_entropy(prob_expert, th.ones_like(prob_expert))
-                + F.binary_cross_entropy(prob_agent, th.zeros_like(prob_agent)))
-        coefs = th.autograd.grad(loss, losses)
-        self.discriminator_optimizer.zero_grad()
-        roots, grads = [], []
-        for call, cf in zip(calls, coefs):
-            r, g = call.backward(cf, d.R1_LAMBDA)
+                calls.append(mlp_device.DiffusionLossCall(d, c, o, a_, self.n_actions, t, noise))
+        # Per data set three launches: the condition-1 loss lp (forward only); condition 0 forward + backward, which
+        # needs lp for its rows' BCE coefficients and leaves ln; condition 1 forward + backward with ln.  (A row's
+        # coefficient depends on both of its losses, so one of the two forwards runs twice.)
+        roots, grads, probs = [], [], []
+        for (call_p, call_n), label in (((calls[0], calls[1]), 1), ((calls[2], calls[3]), 0)):
+            lp = call_p.loss(d.R1_LAMBDA)
+            r, g, ln = call_n.backward_bce(lp, 1, label, 1.0 / rows, d.R1_LAMBDA)
             roots += r
             grads += g
+            r, g, _ = call_p.backward_bce(ln, 0, label, 1.0 / rows, d.R1_LAMBDA)
+            roots += r
+            grads += g
+            probs.append(th.exp(-lp) / (th.exp(-lp) + th.exp(-ln) + 1e-8))
+        prob_expert, prob_agent = probs
+        loss = (F.binary_cross_entropy(prob_expert, th.ones_like(prob_expert))
+                + F.binary_cross_entropy(prob_agent, th.zeros_like(prob_agent)))
+        self.discriminator_optimizer.zero_grad()
         th.autograd.backward(roots, grads)
         all_reduce_grads_(list(d.parameters()), average=True)
         self.discriminator_optimizer.step()

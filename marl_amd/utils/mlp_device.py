@@ -188,6 +188,32 @@ class DiffusionLossCall:
             raise ValueError("coef rows mismatch")
         flat = th.zeros(H * SA + 2 * H + H * H + H + SA * H + SA + H, dtype=th.float32, device=self.obs.device)
         self._launch(coef, None, flat, r1_lambda)
+        return self._unpack(flat)
+
+    def backward_bce(self, other_loss, side, label, scale, r1_lambda=1e-4):
+        """The backward with the coefficient taken in the kernel (ec_diffusion_grad_bce): d BCE(D_phi, label) / d loss[r]
+        with D_phi = exp(-lp) / (exp(-lp) + exp(-ln) + 1e-8) (dgail_agent.py:209-221), this call being lp (side 0) or ln
+        (side 1) and `other_loss` [rows] the other one; scale = 1 / rows of the BCE's mean.  Returns (tensors, gradients,
+        this call's per-row loss)."""
+        SA, H = self.SA, self.H
+        other_loss = _f32(other_loss, "other_loss").reshape(-1)
+        if other_loss.shape[0] != self.rows:
+            raise ValueError("other_loss rows mismatch")
+        dev = self.obs.device
+        flat = th.zeros(H * SA + 2 * H + H * H + H + SA * H + SA + H, dtype=th.float32, device=dev)
+        loss = th.empty((self.rows,), dtype=th.float32, device=dev)
+        w1, bias_t, w2, b2, w3, b3, w3sum = self._dev
+        with th.cuda.device(dev):
+            _abi.check(_abi.lib().ec_diffusion_grad_bce(
+                _p(w1), int(w1.shape[1]), _p(bias_t), _p(w2), _p(b2), _p(w3), _p(b3), _p(w3sum), _p(self.obs),
+                _p(self.actions), _p(self.t), _p(self.noise), _p(other_loss), int(side), int(label), C.c_float(scale),
+                self.rows, int(self.n_actions), int(self.H), C.c_float(r1_lambda), _p(loss), _p(flat), _stream(dev)),
+                "ec_diffusion_grad_bce")
+        tensors, grads = self._unpack(flat)
+        return tensors, grads, loss
+
+    def _unpack(self, flat):
+        SA, H = self.SA, self.H
         o = 0
 
         def take(n, shape):

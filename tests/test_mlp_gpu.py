@@ -320,6 +320,42 @@ def test_diffusion_grad(n_actions, rows, c, train):
         assert err <= 2e-4 * scale + 1e-9, (name, err, scale)
 
 
+@pytest.mark.parametrize("n_actions,rows,label", [(11, 5000, 1), (11, 5000, 0), (41, 2000, 0)])
+def test_diffusion_grad_bce_coefficient(n_actions, rows, label):
+    """ec_diffusion_grad_bce (the BCE coefficient of D_phi taken in the kernel from the two conditions' per-row losses)
+    == ec_diffusion_grad with the coefficient torch autograd derives from F.binary_cross_entropy(D_phi, label), for both
+    sides of a data set, expert and agent labels; the losses it leaves are the forward launch's."""
+    import torch.nn.functional as F
+    from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import DiffusionDiscriminator
+    from marl_amd.utils import mlp_device
+    dev = _dev()
+    SA = 9 + n_actions
+    th.manual_seed(7 + n_actions)
+    net = DiffusionDiscriminator(SA, 64).eval().to(dev)
+    gen = th.Generator().manual_seed(rows + label)
+    obs = _obs(rows, gen).to(dev)
+    actions = th.randint(0, n_actions, (rows,), generator=gen).to(dev)
+    calls = []
+    for c in (1, 0):
+        t = th.randint(0, 2, (rows,), generator=gen).to(dev)
+        noise = th.randn(rows, SA, generator=gen).to(dev)
+        calls.append(mlp_device.DiffusionLossCall(net, c, obs, actions, n_actions, t, noise))
+    lam = 0.01
+    lp = calls[0].loss(lam).requires_grad_(True)
+    ln = calls[1].loss(lam).requires_grad_(True)
+    prob = th.exp(-lp) / (th.exp(-lp) + th.exp(-ln) + 1e-8)
+    loss = F.binary_cross_entropy(prob, th.full_like(prob, float(label)))
+    cp, cn = th.autograd.grad(loss, (lp, ln))
+    assert float(cp.abs().max()) > 0 and float(cn.abs().max()) > 0
+    for call, coef, other, side, own in ((calls[0], cp, ln, 0, lp), (calls[1], cn, lp, 1, ln)):
+        _, want = call.backward(coef, lam)
+        _, got, loss_out = call.backward_bce(other.detach(), side, label, 1.0 / rows, lam)
+        assert th.equal(loss_out, own.detach())
+        for w, g in zip(want, got):
+            scale = float(w.abs().max())
+            assert float((w - g).abs().max()) <= 1e-4 * scale + 1e-9, (side, scale)
+
+
 def test_diffusion_grad_rejects():
     from marl_amd import _abi
     from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import DiffusionDiscriminator
