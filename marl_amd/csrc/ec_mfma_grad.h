@@ -15,20 +15,29 @@ constexpr int TILE = 64 * TSTR;          // floats per tile
 
 // out[to] += frag * f(in): TI input tiles of 16 accumulator registers (k order kperm), one group of 32 rows.
 // KQ: live 4-register groups of the LAST input tile (the k-steps of the others multiply zeros and are skipped).
+// The fragment word of a group of four MFMAs is requested one group AHEAD: a wave alone on its SIMD issues in order, so
+// a ds_read placed between two groups is waited for with the matrix pipe draining (≈100 cycles per 256 of MFMA); the
+// sched_group_barriers keep the compiler from sinking the read back to its use.
 template <int TO, int TI, int KQ = 4, typename F>
 __device__ __forceinline__ void chain(f32x16 (&out)[TO], const float* __restrict__ frag, const f32x16 (&in)[TI], int lane, F f) {
+    constexpr int NG = (4 * (TI - 1) + KQ) * TO;  // groups of four MFMAs = fragment words
+    float4 nxt = *reinterpret_cast<const float4*>(frag + lane * 4);
 #pragma unroll
-    for (int s4 = 0; s4 < 4 * (TI - 1) + KQ; s4++) {
+    for (int g = 0; g < NG; g++) {
+        const int s4 = g / TO, to = g - s4 * TO;
+        const float4 a = nxt;
+        if (g + 1 < NG) nxt = *reinterpret_cast<const float4*>(frag + ((g + 1) * 64 + lane) * 4);
+        const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-        for (int to = 0; to < TO; to++) {
-            const float4 a = *reinterpret_cast<const float4*>(frag + ((s4 * TO + to) * 64 + lane) * 4);
-            const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int T = s4 >> 2, r = (s4 & 3) * 4 + c;
-                out[to] = MFMA(av[c], f(T, r, in[T][r]), out[to]);
-            }
+        for (int c = 0; c < 4; c++) {
+            const int T = s4 >> 2, r = (s4 & 3) * 4 + c;
+            out[to] = MFMA(av[c], f(T, r, in[T][r]), out[to]);
         }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read (the next group's word)
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
     }
 }
 
