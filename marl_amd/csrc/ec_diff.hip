@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
         put_tile<TX>(Td, e, lane, ident);
         put_tile<2>(Ta, h2, lane, relu_f);
         wave_sync();
-        wgrad<TX, 2>(gW3, gb3, Td, Ta, lane);
+        wgrad<TX, 2, 4, TX == 1>(gW3, gb3, Td, Ta, lane);
         f32x16 d2[2];
         acc_zero<2>(d2);
         chain<2, TX>(d2, s_f3t, e, lane, ident);
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
         put_tile<2>(Td, v2, lane, sel1);
         put_tile<TX>(Ta, g, lane, ident);
         wave_sync();
-        wgrad<2, TX>(gW1, nob, Td, Ta, lane);
+        wgrad<2, TX, 4, TX == 1>(gW1, nob, Td, Ta, lane);
         f32x16 dv2[2];
         acc_zero<2>(dv2);
         chain<2, TX>(dv2, s_f1, g, lane, ident);
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
         put_tile<2>(Td, w3s, lane, sel2);
         put_tile<2>(Ta, dv2, lane, ident);
         wave_sync();
-        wgrad<2, 2>(gW2, nob, Td, Ta, lane);
+        wgrad<2, 2, 4, TX == 1>(gW2, nob, Td, Ta, lane);
         {
             f32x16 du2[2];
             acc_zero<2>(du2);
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
         put_tile<2>(Td, d2, lane, ident);
         put_tile<2>(Ta, h1, lane, relu_f);
         wave_sync();
-        wgrad<2, 2>(gW2, gb2, Td, Ta, lane);
+        wgrad<2, 2, 4, TX == 1>(gW2, gb2, Td, Ta, lane);
         f32x16 d1[2];
         acc_zero<2>(d1);
         chain<2, 2>(d1, s_f2t, d2, lane, ident);
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
         for (int in = half; in < 32 * TX; in += 2)
             Ta[in * TSTR + jrow] = in < SA ? s_x[jrow * SAp + in] : (in == SA ? (float)tr : 0.0f);
         wave_sync();
-        wgrad<2, TX>(gW1, gb1, Td, Ta, lane);
+        wgrad<2, TX, 4, TX == 1>(gW1, gb1, Td, Ta, lane);
     }
 
     if (BWD && nw > 1) {  // wave 0 collects the block's sums and is the only one to flush them (see block_sum)

@@ -77,28 +77,60 @@ __device__ __forceinline__ void put_tile(float* __restrict__ tile, const f32x16 
 
 // acc[to][ti] += Td[out][row] (x) Ta[in][row] over the tile's 32 rows; dbias[to] += sum_rows Td[out][row] (lane's parity)
 // UNR = 16: straight-line code, for a call site whose surroundings are to be scheduled between the MFMAs
-template <int TO, int TI, int UNR = 4>
+// AHEAD: request the operands of step s + 1 before the MFMAs of step s (for instantiations with registers to spare)
+template <int TO, int TI, int UNR = 4, bool AHEAD = true>
 __device__ __forceinline__ void wgrad(f32x16 (&acc)[TO][TI], float (&dbias)[TO], const float* __restrict__ Td,
                                       const float* __restrict__ Ta, int lane) {
 #ifdef ABL_NO_WGRAD
     return;
 #endif
     const int i = lane & 31, half = lane >> 5;
+    if constexpr (!AHEAD) {
+#pragma unroll UNR
+        for (int s = 0; s < 16; s++) {
+            const int row = 2 * s + half;
+            float a[TO], b[TI];
+#pragma unroll
+            for (int to = 0; to < TO; to++) {
+                a[to] = Td[(32 * to + i) * TSTR + row];
+                dbias[to] += a[to];
+            }
+#pragma unroll
+            for (int ti = 0; ti < TI; ti++) b[ti] = Ta[(32 * ti + i) * TSTR + row];
+#pragma unroll
+            for (int to = 0; to < TO; to++)
+#pragma unroll
+                for (int ti = 0; ti < TI; ti++) acc[to][ti] = MFMA(a[to], b[ti], acc[to][ti]);
+        }
+        return;
+    }
+    // operands of step s + 1 are requested before the MFMAs of step s (see chain(): an LDS round trip between two
+    // steps is otherwise waited for with the matrix pipe idle)
+    float an[TO], bn[TI];
+#pragma unroll
+    for (int to = 0; to < TO; to++) an[to] = Td[(32 * to + i) * TSTR + half];
+#pragma unroll
+    for (int ti = 0; ti < TI; ti++) bn[ti] = Ta[(32 * ti + i) * TSTR + half];
 #pragma unroll UNR
     for (int s = 0; s < 16; s++) {
-        const int row = 2 * s + half;
         float a[TO], b[TI];
 #pragma unroll
-        for (int to = 0; to < TO; to++) {
-            a[to] = Td[(32 * to + i) * TSTR + row];
-            dbias[to] += a[to];
-        }
+        for (int to = 0; to < TO; to++) a[to] = an[to];
 #pragma unroll
-        for (int ti = 0; ti < TI; ti++) b[ti] = Ta[(32 * ti + i) * TSTR + row];
+        for (int ti = 0; ti < TI; ti++) b[ti] = bn[ti];
+        const int row = 2 * (s < 15 ? s + 1 : 15) + half;  // (the last step re-reads its own row: no branch)
+#pragma unroll
+        for (int to = 0; to < TO; to++) an[to] = Td[(32 * to + i) * TSTR + row];
+#pragma unroll
+        for (int ti = 0; ti < TI; ti++) bn[ti] = Ta[(32 * ti + i) * TSTR + row];
+#pragma unroll
+        for (int to = 0; to < TO; to++) dbias[to] += a[to];
 #pragma unroll
         for (int to = 0; to < TO; to++)
 #pragma unroll
             for (int ti = 0; ti < TI; ti++) acc[to][ti] = MFMA(a[to], b[ti], acc[to][ti]);
+        __builtin_amdgcn_sched_group_barrier(0x100, TO + TI, 0);   // the next step's DS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, TO * TI, 0);   // this step's MFMAs
     }
 }
 

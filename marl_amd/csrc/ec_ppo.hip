@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
     // trip -- measured 20 % of a pass (observation tile, then target / advantage / old log-prob / mask / action each
     // behind its own wait).  The forward-only passes run two waves per SIMD and keep their registers: they fetch in place.
     constexpr bool PF = BWD && (HEAD == 1 || (TO3 == 1 && IN1T == 1));  // (the wider actor instantiations have no registers to spare)
+    constexpr bool WA = PF;  // weight-gradient operands one step ahead: the same instantiations have the registers for it
     constexpr int AVP = (HEAD == 0 && PF) ? 6 : 0;  // prefetched mask words per lane (32 x A <= 384); the rest in place
     struct Pre {
         float obs[5];  // 32 x 9 floats over 64 lanes
@@ -267,7 +268,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             acc_init<T3>(z, s_b3, half);
             chain<T3, 2>(z, s_f3, h2, lane, [](int, int, float x) { return relu(x); });
             PST(2);
-            if (BWD) wgrad<2, IN1T, 16>(gW1, gb1, Td, Ta, lane);  // the previous tile's dW1 (see above)
+            if (BWD) wgrad<2, IN1T, 16, WA>(gW1, gb1, Td, Ta, lane);  // the previous tile's dW1 (see above)
             // ---- head: masked softmax, Categorical log-prob / entropy, clipped surrogate (ppo_agent.py:76-83,135-141)
             const int act = cur.act;
             const bool clampp = !(p.flags & EC_PPO_LOGITS);
@@ -370,14 +371,14 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
             put_tile<2>(Ta, h2, lane, [](int, int, float x) { return relu(x); });
             wave_sync();
             PST(4);
-            wgrad<T3, 2>(gW3, gb3, Td, Ta, lane);
+            wgrad<T3, 2, 4, WA>(gW3, gb3, Td, Ta, lane);
             PST(5);
             // d2 = (W3^T d3) .* [h2 > 0]
             acc_zero<2>(d2);
             chain<2, T3, NQ>(d2, s_f3t, z, lane, [](int, int, float x) { return x; });
         } else {
             // ---- critic head: v = w3 . relu(h2) + b3 ; loss = ((v - target) * mask)^2 / denom (ppo_agent.py:124-125)
-            if (BWD) wgrad<2, IN1T, 16>(gW1, gb1, Td, Ta, lane);  // the previous tile's dW1 (see above)
+            if (BWD) wgrad<2, IN1T, 16, WA>(gW1, gb1, Td, Ta, lane);  // the previous tile's dW1 (see above)
             float part = 0.0f;
 #pragma unroll
             for (int t = 0; t < 2; t++)
@@ -436,7 +437,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
         put_tile<2>(Ta, h1, lane, [](int, int, float x) { return relu(x); });
         wave_sync();
         PST(4);
-        wgrad<2, 2>(gW2, gb2, Td, Ta, lane);
+        wgrad<2, 2, 4, WA>(gW2, gb2, Td, Ta, lane);
         PST(5);
         // d1 = (W2^T d2) .* [h1 > 0]
         f32x16 d1[2];
@@ -455,7 +456,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
         wave_sync();
         PST(4);
     }
-    if (BWD) wgrad<2, IN1T>(gW1, gb1, Td, Ta, lane);
+    if (BWD) wgrad<2, IN1T, 4, WA>(gW1, gb1, Td, Ta, lane);
 #ifdef ABL_PPO_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0 && BWD && n_tiles > 10000)
         printf("k_ppo<head %d> cycles per section, wave 0 of block 0: load %llu | fwd L1+L2 %llu | L3 %llu | head %llu | put %llu | "
