@@ -473,3 +473,21 @@ def test_tall_bn_relu_dropout_node_matches_modules(monkeypatch):
     for a, b in ((out_a, out_b), (xa.grad, xb.grad), (stock.weight.grad, tall.weight.grad), (stock.bias.grad, tall.bias.grad),
                  (stock.running_mean, tall.running_mean), (stock.running_var, tall.running_var)):
         assert th.allclose(a.detach(), b.detach(), rtol=1e-10, atol=1e-11), (a - b).abs().max()
+
+
+def test_clip_adam_step_declines_on_cpu_and_leaves_everything_alone():
+    """optim_device.clip_adam_step is a device path only: for CPU parameters (and for anything that is not a plain fp32
+    Adam) it returns False without touching parameters, gradients or optimiser state, and the caller's torch path runs."""
+    import torch as th
+    from marl_amd.utils import optim_device
+    net = th.nn.Linear(4, 3)
+    for p in net.parameters():
+        p.grad = th.ones_like(p)
+    before = [p.detach().clone() for p in net.parameters()]
+    for opt in (th.optim.Adam(net.parameters(), lr=1e-2), th.optim.Adam(net.parameters(), lr=1e-2, weight_decay=0.1),
+                th.optim.SGD(net.parameters(), lr=1e-2)):
+        assert optim_device.clip_adam_step([opt], 1.0) is False
+        assert len(opt.state) == 0
+    assert optim_device.clip_adam_step([], 1.0) is False
+    assert all(th.equal(a, b) for a, b in zip(before, net.parameters()))
+    assert all(bool((p.grad == 1).all()) for p in net.parameters())
