@@ -696,3 +696,46 @@ def test_expert_append_episode_equals_per_step_appends(B, T, cap, ratio):
         n = len(b)
         assert len(a) == n
         assert th.equal(a.obs[:n], b.obs[:n]) and th.equal(a.actions[:n], b.actions[:n]), rep
+
+
+@pytest.mark.gpu
+def test_guided_rollout_entry_points_reject_bad_arguments():
+    """ec_rollout_mlp_expert_policy / ec_expert_append_episode / ec_adam_clip_step say what is wrong instead of launching:
+    coin without ratios, wrong shapes, a missing workspace, too many networks."""
+    import ctypes as C
+    import torch as th
+    from marl_amd import _abi
+    from marl_amd.buffer.expert_transitions import ExpertTransitions
+    from marl_amd.envs.env_register import env_register
+    a = _imitation_args("gail", 4, episode_limit=10)
+    env = env_register["edge_computing_batched"](a, n_envs=4)
+    env.reset()
+    N = a.n_agents
+    dev = env.device
+    params = tuple(th.zeros(*d, device=dev) for d in [(64, 9 + N), (64,), (64, 64), (64,), (N + 1, 64), (N + 1,)])
+    coin = th.rand(3, 4, device=dev)
+    with pytest.raises(ValueError, match="go together"):
+        env.rollout_mlp_policy(params, 3, coin=coin)
+    with pytest.raises(ValueError, match="ratios"):
+        env.rollout_mlp_policy(params, 3, coin=coin, ratios=th.ones(4, device=dev))
+    with pytest.raises(ValueError, match="coin"):
+        env.rollout_mlp_policy(params, 3, coin=coin.double(), ratios=th.ones(3, device=dev))
+    hist = env.rollout_mlp_policy(params, 3, coin=coin, ratios=th.ones(3, device=dev))       # the well-formed call works
+    assert hist["expert_actions"].shape == (3, 4, N)
+    L = _abi.lib()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    null = C.c_void_p(0)
+    ring = ExpertTransitions(8, N, 9, dev)
+    rc = L.ec_expert_append_episode(vp(coin), vp(th.ones(3, device=dev)), vp(hist["expert_actions"]), vp(env.obs), vp(hist["obs"]),
+                                    3, 4, N, 9, 8, vp(ring.obs), vp(ring.actions), vp(ring._written), null, null, null)
+    assert rc != 0 and b"null" in L.ec_last_error()
+    with pytest.raises(ValueError, match="shapes"):
+        ring.append_episode(coin, th.ones(2, device=dev), hist["expert_actions"], env.obs, hist["obs"])
+    assert int(ring._written) == 0
+    ring.append_episode(coin, th.ones(3, device=dev), hist["expert_actions"], env.obs, hist["obs"])   # ratio 1: every env, every step
+    assert int(ring._written) == 12 and len(ring) == 8
+    assert th.equal(ring.actions[(12 - 1) % 8], hist["expert_actions"][2, 3])                # the newest entry is (t=2, b=3)
+    n5 = (C.c_int32 * 5)(1, 1, 1, 1, 1)
+    assert L.ec_adam_clip_step(5, n5, null, null, null, null, null, null, null, null, null, null, null, null, null) != 0
+    assert b"networks" in L.ec_last_error()
+    env.close()
