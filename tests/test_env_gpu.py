@@ -551,17 +551,22 @@ def test_rollout_mlp_policy_unsupported_shape_is_an_error():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,expert,greedy,geometry", [(21, False, False, None), (21, True, False, None), (9, False, True, None),
-                                                      (13, True, False, (1, 2, 0)), (13, False, False, (1, 1, 0))])
-def test_rollout_mlp_policy_40_nodes(monkeypatch, B, expert, greedy, geometry):
+@pytest.mark.parametrize("B,expert,greedy,geometry,nodes", [(21, False, False, None, 40), (21, True, False, None, 40),
+                                                            (9, False, True, None, 40), (13, True, False, (1, 2, 0), 40),
+                                                            (13, False, False, (1, 1, 0), 40), (7, True, False, None, 56),
+                                                            (7, False, False, (1, 1, 0), 63)])
+def test_rollout_mlp_policy_40_nodes(monkeypatch, B, expert, greedy, geometry, nodes):
     """The 40-node topology of BASELINE configs[4] (41 actions: two output tiles in the Actor's last layer) through the
     looping kernel, plain and expert-guided, == the per-step launches (ec_policy_forward, ec_expert_policy, ec_step), bit
     for bit, in chunks of 30 steps over two episodes; with and without RNG producer waves (the rows of a 40-lane main wave
     beyond its first 32 go to a producer wave when there is one)."""
     th = _th()
     from marl_amd.utils import mlp_device
-    g = load_golden("env40")
-    args = args_from_golden(g)
+    if nodes == 40:
+        args = args_from_golden(load_golden("env40"))
+    else:  # 57 / 64 actions: the epilogue instantiation for 49..64 actions (the 40-node one covers 33..48)
+        from tests.util import make_args
+        args = make_args(["--edge_node_num=%d" % nodes, "--task_size_max=6000", "--seed=5", "--episode_limit=40"])
     N, T = args.edge_node_num, args.episode_limit
     ref_env = _make_env(args, B, 2)
     if geometry:
@@ -569,7 +574,7 @@ def test_rollout_mlp_policy_40_nodes(monkeypatch, B, expert, greedy, geometry):
             monkeypatch.setenv(key, str(v))
     env = _make_env(args, B, 2)
     geo = env.info_geometry()
-    assert geo["rollout_mlp_policy"] and geo["rollout_mlp_expert_policy"]
+    assert geo["rollout_mlp_policy"] and geo["rollout_mlp_expert_policy"], geo
     if geometry:
         assert (geo["envs_per_wave"], geo["main_waves"], geo["rng_producer_waves"] > 0) == geometry[:2] + (bool(geometry[2]),)
     dev = env.device
