@@ -78,6 +78,10 @@ def test_hip_layer_tail_own_mask():
     cols, rws = kept.float().mean(0), kept.float().mean(1)          # no column or row pattern
     assert float(cols.min()) > 0.69 and float(cols.max()) < 0.71
     assert float(rws.min()) > 0.45 and float(rws.max()) < 0.92
+    # neighbours in a row, neighbours in a column and the two seeds are independent draws: P(both kept) = (1 - p)^2
+    k, o = kept.float(), (other > 0).float()
+    for both in ((k[:, 1:] * k[:, :-1]).mean(), (k[1:] * k[:-1]).mean(), (k * o).mean()):
+        assert abs(float(both) - (1 - p) ** 2) < 2e-3, float(both)
 
 
 @pytest.mark.gpu
