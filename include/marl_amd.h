@@ -445,6 +445,14 @@ int ec_adam_clip_step(int32_t n_nets, const int32_t* n_tensors, float* const* pa
  *             caller from the sums and the statistics)
  * keep: `mask` [rows, C] u8 when given, else a counter-based Bernoulli(1 - p) draw from (seed, element index) that the
  * backward recomputes instead of reading.  Replaces F.batch_norm / relu / F.dropout and their autograd backward. */
+/* Weight and bias gradient of a Linear layer over a tall batch (gail_network.py:97-125, the discriminator's layers on
+ * 4.1 M .. 65.5 M rows): dW [c_out, k_in] = dy^T x, db [c_out] = sum_rows dy for dy [rows, c_out], x [rows, k_in] fp32,
+ * c_out in {32, 64, 96, 128}, k_in <= 128.  partials [n_partials][c_out * k_in + c_out] <- per-block sums (dW row-major,
+ * then db); the caller adds them up.  One read of dy and x, the row index as the MFMA's K dimension.  Replaces
+ * dy.t() @ x and dy.sum(0) of torch's Linear backward. */
+int ec_linear_wgrad(const float* dy, const float* x, int64_t rows, int32_t c_out, int32_t k_in, int32_t n_partials,
+                    float* partials, void* stream);
+
 /* The batch statistics of the same layer in one streaming pass: partials [n_partials][2][C] <- per-block sums over rows of
  * (x - x[0]) and (x - x[0])^2 per column (row 0 as the pivot); the caller adds the partials up (in float64) and takes
  * mean = x[0] + S1/n, biased var = S2/n - (S1/n)^2.  Replaces torch.var_mean(x, dim=0). */

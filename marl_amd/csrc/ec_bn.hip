@@ -255,3 +255,140 @@ int ec_bn_relu_dropout_bwd_dx(const float* dout, const float* x, const float* sc
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a Linear layer over a tall batch: dW [Cout, K] = dy^T x, db [Cout] = sum_rows dy, for dy [rows, Cout],
+// x [rows, K] fp32 with Cout a multiple of 32 up to 128 and K <= 128 (gail_network.py:97-125: 30/50 -> 128 -> 64 -> 32 on
+// 4.1 M .. 65.5 M rows).  torch hands [Cout, rows] x [rows, K] to a GEMM whose contraction length is the row count; even
+// chunked into a batched GEMM + sum it runs at a fifth of the HBM rate.  Here the row index is the MFMA's K dimension, as
+// in the fused learner kernels, but the operands come straight from global memory: at step s the lanes of half h read 32
+// consecutive floats of row 2 s + h of dy and of x (coalesced), and every (output tile, input tile) pair takes one
+// 32x32x2 MFMA into a persistent accumulator.  One read of dy and x; per-block partial sums, added up by the caller.
+namespace {
+
+typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgArgs {
+    const float* dy;  // [rows, Cout]
+    const float* x;   // [rows, K]
+    int64_t rows;
+    int Cout, K;
+    float* partials;  // [blocks][Cout * K + Cout]
+};
+
+template <int TO, int TI>
+__global__ void __launch_bounds__(256) k_linear_wgrad(WgArgs p) {
+    __shared__ float s_red[TO * TI * 16 + TO][64];  // one wave's accumulators at a time (wave 0 adds them up, in wave order)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, half = lane >> 5;
+    const int nw = blockDim.x >> 6;
+    wg_f32x16 acc[TO][TI];
+    float db[TO];
+#pragma unroll
+    for (int to = 0; to < TO; to++) {
+        db[to] = 0.0f;
+#pragma unroll
+        for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[to][ti][r] = 0.0f;
+    }
+    // rows are dealt out in chunks of 64 (32 steps) to the grid's waves
+    const int64_t n_chunks = (p.rows + 63) / 64;
+    for (int64_t chunk = (int64_t)blockIdx.x * nw + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * nw) {
+        const int64_t r0 = chunk * 64;
+        constexpr int U = 8;  // steps whose loads are issued together
+#pragma unroll 1
+        for (int s0 = 0; s0 < 32; s0 += U) {
+            float a[U][TO], b[U][TI];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t row = r0 + 2 * (s0 + u) + half;
+                const bool ok = row < p.rows;
+#pragma unroll
+                for (int to = 0; to < TO; to++) a[u][to] = ok ? p.dy[row * p.Cout + 32 * to + i] : 0.0f;
+#pragma unroll
+                for (int ti = 0; ti < TI; ti++) b[u][ti] = (ok && 32 * ti + i < p.K) ? p.x[row * p.K + 32 * ti + i] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+#pragma unroll
+                for (int to = 0; to < TO; to++) {
+                    db[to] += a[u][to];
+#pragma unroll
+                    for (int ti = 0; ti < TI; ti++)
+                        acc[to][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][to], b[u][ti], acc[to][ti], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // block reduction in a fixed order (wave 1, 2, 3 into wave 0), then the block's partial sums
+    for (int w = 1; w < nw; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int to = 0; to < TO; to++) {
+#pragma unroll
+                for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) s_red[(to * TI + ti) * 16 + r][lane] = acc[to][ti][r];
+                s_red[TO * TI * 16 + to][lane] = db[to];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int to = 0; to < TO; to++) {
+#pragma unroll
+                for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[to][ti][r] += s_red[(to * TI + ti) * 16 + r][lane];
+                db[to] += s_red[TO * TI * 16 + to][lane];
+            }
+        }
+        __syncthreads();
+    }
+    if (wave > 0) return;
+    float* out = p.partials + (size_t)blockIdx.x * ((size_t)p.Cout * p.K + p.Cout);
+#pragma unroll
+    for (int to = 0; to < TO; to++) {
+#pragma unroll
+        for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                // accumulator register r of lane (i, half): output 32 to + 8 (r >> 2) + 4 half + (r & 3), input 32 ti + i
+                const int o = 32 * to + 8 * (r >> 2) + 4 * half + (r & 3), k = 32 * ti + i;
+                if (k < p.K) out[(size_t)o * p.K + k] = acc[to][ti][r];
+            }
+        const float v = db[to] + __shfl_xor(db[to], 32);  // the two halves hold the two row parities of the same output
+        if (half == 0) out[(size_t)p.Cout * p.K + 32 * to + i] = v;
+    }
+}
+
+template <int TO>
+int launch_wgrad_ti(const WgArgs& a, int TI, int blocks, hipStream_t stream) {
+    switch (TI) {
+        case 1: hipLaunchKernelGGL((k_linear_wgrad<TO, 1>), dim3(blocks), dim3(256), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((k_linear_wgrad<TO, 2>), dim3(blocks), dim3(256), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((k_linear_wgrad<TO, 3>), dim3(blocks), dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL((k_linear_wgrad<TO, 4>), dim3(blocks), dim3(256), 0, stream, a); break;
+    }
+    return EC_OK;
+}
+
+}  // namespace
+
+extern "C" int ec_linear_wgrad(const float* dy, const float* x, int64_t rows, int32_t c_out, int32_t k_in, int32_t n_partials,
+                               float* partials, void* stream) {
+    if (!dy || !x || !partials) return ec::fail(EC_EINVAL, "ec_linear_wgrad: null pointer");
+    if (rows < 0 || c_out < 32 || c_out > 128 || (c_out & 31) || k_in < 1 || k_in > 128 || n_partials < 1 || n_partials > 65535)
+        return ec::fail(EC_EINVAL, "ec_linear_wgrad: rows %lld, c_out %d (32, 64, 96 or 128), k_in %d (1..128), n_partials %d",
+                        (long long)rows, c_out, k_in, n_partials);
+    const WgArgs a{dy, x, rows, c_out, k_in, partials};
+    const int TI = (k_in + 31) / 32;
+    switch (c_out / 32) {
+        case 1: launch_wgrad_ti<1>(a, TI, n_partials, (hipStream_t)stream); break;
+        case 2: launch_wgrad_ti<2>(a, TI, n_partials, (hipStream_t)stream); break;
+        case 3: launch_wgrad_ti<3>(a, TI, n_partials, (hipStream_t)stream); break;
+        default: launch_wgrad_ti<4>(a, TI, n_partials, (hipStream_t)stream); break;
+    }
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}

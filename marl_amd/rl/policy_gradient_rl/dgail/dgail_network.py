@@ -7,6 +7,8 @@ import torch as th
 import torch.nn as nn
 import torch.nn.functional as F
 
+from marl_amd.utils import linear_device
+
 
 def _chunked_tn(a, b, chunk):
     """a^T @ b for tall a [rows, m], b [rows, n], reduced in row chunks (a batched GEMM + a small sum)."""
@@ -54,7 +56,10 @@ class _SplitKLinearFn(th.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = _TallMatmulFn.apply(gy, w) if th.is_grad_enabled() else gy @ w
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and linear_device.wgrad_ok(gy, x):
+            # one pass over gy and x with the row index as the MFMA's K dimension (ec_linear_wgrad)
+            gw, gb = linear_device.wgrad(gy, x)
+        elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             rows = gy.shape[0]
             c = _SplitKLinearFn.CHUNK
             full = (rows // c) * c

@@ -131,8 +131,10 @@ class GAILAgent:
         onehot = F.one_hot(actions.squeeze(-1), num_classes=a.n_actions).float()
         e_obs, e_act = self.expert_transitions.sample_transitions(64)
         expert_logits = self.discriminator(self._with_ids(e_obs), F.one_hot(e_act, num_classes=a.n_actions).float())
-        flat_obs, flat_act = obs_id.reshape(-1, obs_id.size(-1)), onehot.reshape(-1, onehot.size(-1))
-        agent_logits = self.discriminator(flat_obs, flat_act)
+        # the agent rows (obs | id | one-hot action), built once for the training pass and the reward pass below
+        agent_rows = self.discriminator.rows(obs_id.reshape(-1, obs_id.size(-1)), onehot.reshape(-1, onehot.size(-1)))
+        del onehot
+        agent_logits = self.discriminator.forward_rows(agent_rows)
         bce = nn.BCEWithLogitsLoss()
         loss = bce(agent_logits.reshape(-1, 1), th.ones_like(agent_logits.reshape(-1, 1))) + \
             bce(expert_logits, th.zeros_like(expert_logits))
@@ -143,7 +145,7 @@ class GAILAgent:
             th.nn.utils.clip_grad_norm_(self.discriminator.parameters(), a.grad_norm_clip)
         self.discriminator_optimizer.step()
         with th.no_grad():
-            x = self.discriminator(flat_obs, flat_act).reshape(B, T, N, 1)
+            x = self.discriminator.forward_rows(agent_rows).reshape(B, T, N, 1)
             rewards = -F.logsigmoid(x) + F.logsigmoid(-x)
         self.last_losses["discriminator_loss"] = loss.detach()
         return rewards

@@ -1,0 +1,29 @@
+"""Host side of ec_linear_wgrad (include/marl_amd.h): the weight / bias gradient of a Linear layer over a tall batch."""
+import ctypes as C
+
+import torch as th
+
+from marl_amd import _abi
+
+N_PARTIALS = 512  # blocks of four waves: two per CU
+
+
+def wgrad_ok(gy, x):
+    return (gy.is_cuda and x.is_cuda and gy.dtype == th.float32 and x.dtype == th.float32 and gy.dim() == 2 and x.dim() == 2
+            and gy.shape[0] == x.shape[0] and gy.shape[1] in (32, 64, 96, 128) and 1 <= x.shape[1] <= 128
+            and not th.is_grad_enabled())
+
+
+def wgrad(gy, x):
+    """(gy^T @ x [c_out, k_in], gy.sum(0) [c_out]) in one pass over gy [rows, c_out] and x [rows, k_in]"""
+    gy, x = gy.contiguous(), x.contiguous()
+    rows, c_out = gy.shape
+    k_in = x.shape[1]
+    n_part = int(min(N_PARTIALS, max(1, (rows + 255) // 256)))
+    partials = th.empty(n_part, c_out * k_in + c_out, dtype=th.float32, device=gy.device)
+    with th.cuda.device(gy.device):
+        _abi.check(_abi.lib().ec_linear_wgrad(C.c_void_p(gy.data_ptr()), C.c_void_p(x.data_ptr()), rows, c_out, k_in, n_part,
+                                              C.c_void_p(partials.data_ptr()),
+                                              C.c_void_p(th.cuda.current_stream(gy.device).cuda_stream)), "ec_linear_wgrad")
+    s = partials.sum(0)
+    return s[:c_out * k_in].view(c_out, k_in), s[c_out * k_in:]

@@ -105,3 +105,34 @@ def test_col_stats_matches_float64(rows, C, offset):
     want_var, want_mean = th.var_mean(x.double(), dim=0, unbiased=False)
     assert th.allclose(mean, want_mean, rtol=1e-6, atol=1e-6)
     assert th.allclose(var, want_var, rtol=2e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,c_out,k_in", [(1, 32, 1), (63, 64, 9), (1000, 128, 30), (100003, 64, 128), (4097, 32, 64),
+                                             (70000, 96, 50), (300000, 128, 128)])
+def test_linear_wgrad_matches_float64(rows, c_out, k_in):
+    """ec_linear_wgrad (dW = dy^T x and db = sum dy over a tall batch, rows as the MFMA's K dimension) against float64:
+    ragged row counts, every tile count, input widths that are not multiples of 32; and through SplitKLinear's backward
+    against nn.Linear's."""
+    import torch as th
+    from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import SplitKLinear
+    from marl_amd.utils import linear_device
+    gen = th.Generator().manual_seed(rows + c_out + k_in)
+    gy = th.randn(rows, c_out, generator=gen).cuda()
+    x = (th.randn(rows, k_in, generator=gen) + 0.5).cuda()
+    with th.no_grad():
+        assert linear_device.wgrad_ok(gy, x)
+        gw, gb = linear_device.wgrad(gy, x)
+    want_w, want_b = gy.double().t() @ x.double(), gy.double().sum(0)
+    tol = 2e-6 * max(1.0, rows ** 0.5)
+    assert float((gw.double() - want_w).abs().max()) <= tol * float(want_w.abs().max() + 1)
+    assert float((gb.double() - want_b).abs().max()) <= tol * float(want_b.abs().max() + 1)
+    if rows >= SplitKLinear.MIN_ROWS:
+        a, b = SplitKLinear(k_in, c_out).cuda(), th.nn.Linear(k_in, c_out).cuda()
+        b.load_state_dict(a.state_dict())
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        (a(xa) * gy).sum().backward()
+        (b(xb) * gy).sum().backward()
+        assert th.allclose(xa.grad, xb.grad, rtol=1e-5, atol=1e-6)
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert float((pa.grad - pb.grad).abs().max()) <= 1e-4 * float(pb.grad.abs().max() + 1)
