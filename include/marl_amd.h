@@ -422,7 +422,7 @@ int ec_expert_append_episode(const float* coin, const float* ratios, const int64
                              void* workspace, void* stream);
 
 /* torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.Adam.step() (no weight decay, no amsgrad) for
- * up to 4 small networks of up to 8 fp32 tensors each in one launch, one block per network: the end of every optimiser
+ * up to 4 small networks of up to 16 fp32 tensors each in one launch, one block per network: the end of every optimiser
  * step of the learners (dgail_agent.py:319-325, ppo_agent.py:128-141, gail_agent.py:222-231), ~40 torch launches otherwise.
  *   n_tensors [n_nets];  params / grads / exp_avg / exp_avg_sq / steps: device pointers, the networks' tensors one after
  *   the other (sum n_tensors entries), numel likewise;  steps: the optimiser's device step counters (capturable Adam;

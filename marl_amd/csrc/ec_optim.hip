@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int ADAM_MAX_TENSORS = 8, ADAM_MAX_NETS = 4;
+constexpr int ADAM_MAX_TENSORS = 16, ADAM_MAX_NETS = 4;  // (the argument block stays under the 4 KB a launch can carry)
 
 struct AdamNet {
     float* p[ADAM_MAX_TENSORS];

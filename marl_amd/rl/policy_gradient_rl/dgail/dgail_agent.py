@@ -231,7 +231,8 @@ class DGAILAgent:
         self.discriminator_optimizer.zero_grad()
         th.autograd.backward(roots, grads)
         all_reduce_grads_(list(d.parameters()), average=True)
-        self.discriminator_optimizer.step()
+        if not optim_device.clip_adam_step([self.discriminator_optimizer], None):   # (no clipping here, :229-233)
+            self.discriminator_optimizer.step()
         self._disc_update_count += 1
         return (float(global_mean(loss.detach().reshape(1))), float(global_mean(prob_expert.detach())),
                 float(global_mean(prob_agent.detach())))
@@ -252,7 +253,8 @@ class DGAILAgent:
                 ppo_device.gail_disc_pass(self.gail_discriminator, o, a_, expert, inv_denom=1.0 / (n * ws),
                                           grads=self._fg_gail.flat, loss=loss)
             all_reduce_sum_(self._fg_gail.flat)
-            self.gail_discriminator_optimizer.step()
+            if not optim_device.clip_adam_step([self.gail_discriminator_optimizer], None):
+                self.gail_discriminator_optimizer.step()
             return float(global_mean(loss * ws))
         if agent_sa is None:
             agent_sa = self._prepare_batch(obs, actions)

@@ -141,9 +141,7 @@ class GAILAgent:
         self.discriminator_optimizer.zero_grad()
         loss.backward()
         all_reduce_grads_(list(self.discriminator.parameters()), average=True)
-        if a.use_grad_clip:
-            th.nn.utils.clip_grad_norm_(self.discriminator.parameters(), a.grad_norm_clip)
-        self.discriminator_optimizer.step()
+        self._clip_and_step(self.discriminator, self.discriminator_optimizer)
         with th.no_grad():
             x = self.discriminator.forward_rows(agent_rows).reshape(B, T, N, 1)
             rewards = -F.logsigmoid(x) + F.logsigmoid(-x)

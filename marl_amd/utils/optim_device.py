@@ -7,7 +7,7 @@ import torch as th
 
 from marl_amd import _abi
 
-MAX_NETS, MAX_TENSORS = 4, 8
+MAX_NETS, MAX_TENSORS = 4, 16
 
 
 def _eligible(opt):
