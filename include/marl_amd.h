@@ -457,6 +457,19 @@ int ec_linear_wgrad(const float* dy, const float* x, int64_t rows, int32_t c_out
  * (x - x[0]) and (x - x[0])^2 per column (row 0 as the pivot); the caller adds the partials up (in float64) and takes
  * mean = x[0] + S1/n, biased var = S2/n - (S1/n)^2.  Replaces torch.var_mean(x, dim=0). */
 int ec_bn_col_stats(const float* x, int64_t rows, int32_t C, int32_t n_partials, float* partials, void* stream);
+/* The per-column arithmetic between those passes, one launch each (float64 sums over the partials):
+ *   ec_bn_finalize: partials of ec_bn_col_stats (+ x_row0 = x[0], its pivot) -> mean, biased var, invstd = rsqrt(var + eps),
+ *     scale = invstd * weight, shift = bias - mean * scale [C]; running_mean / running_var (optional) updated as
+ *     nn.BatchNorm1d does in training mode (momentum < 0: cumulative average with weight 1 / *num_batches_tracked, which the
+ *     caller has advanced for this batch);
+ *   ec_bn_bwd_coeffs: partials of ec_bn_relu_dropout_bwd_sums -> a, b, c of ec_bn_relu_dropout_bwd_dx and
+ *     dweight = sum dy * xhat, dbias = sum dy. */
+int ec_bn_finalize(const float* partials, int32_t n_partials, const float* x_row0, int64_t rows, int32_t C, const float* weight,
+                   const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                   const int64_t* num_batches_tracked, float* mean, float* var, float* invstd, float* scale, float* shift,
+                   void* stream);
+int ec_bn_bwd_coeffs(const float* partials, int32_t n_partials, const float* mean, const float* invstd, const float* weight,
+                     int64_t rows, int32_t C, float* a, float* b, float* c, float* dweight, float* dbias, void* stream);
 int ec_bn_relu_dropout_fwd(const float* x, const float* scale, const float* shift, const uint8_t* mask, uint64_t seed, float p,
                            int64_t rows, int32_t C, float* out, void* stream);
 int ec_bn_relu_dropout_bwd_sums(const float* dout, const float* x, const float* scale, const float* shift, const uint8_t* mask,

@@ -392,3 +392,103 @@ extern "C" int ec_linear_wgrad(const float* dy, const float* x, int64_t rows, in
     EC_HIP(hipGetLastError());
     return EC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The per-column arithmetic between the streaming passes, one launch each instead of ~20 / ~10 tiny torch launches (the
+// 64-row expert batch of a GAIL step is otherwise host-launch-bound, and the big passes enqueue behind it):
+//   ec_bn_finalize     partial sums of ec_bn_col_stats -> mean, biased var, invstd, scale = invstd * weight,
+//                      shift = bias - mean * scale; running statistics updated as nn.BatchNorm1d does in training mode
+//   ec_bn_bwd_coeffs   partial sums of ec_bn_relu_dropout_bwd_sums -> the a, b, c of the dx kernel, dweight, dbias
+// Sums over the partials in float64, one thread per column.
+namespace {
+
+// 8 columns per block, 32 lanes per column: each lane adds up every 32nd partial, the lanes are combined in a fixed
+// shuffle order (a single thread walking 1024 partials per column took ~100 us, on the critical path of every layer)
+__device__ __forceinline__ void column_sums(const float* __restrict__ partials, int n_part, int C, int c, int lane, double& s1,
+                                            double& s2) {
+    s1 = s2 = 0.0;
+    if (c < C)
+        for (int b = lane; b < n_part; b += 32) {
+            s1 += (double)partials[((size_t)b * 2 + 0) * C + c];
+            s2 += (double)partials[((size_t)b * 2 + 1) * C + c];
+        }
+    for (int o = 16; o >= 1; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bn_finalize(const float* __restrict__ partials, int n_part, const float* __restrict__ x0,
+                                                     int64_t rows, int C, const float* __restrict__ weight,
+                                                     const float* __restrict__ bias, float eps, float momentum,
+                                                     float* running_mean, float* running_var, const int64_t* num_batches,
+                                                     float* mean, float* var, float* invstd, float* scale, float* shift) {
+    const int lane = threadIdx.x & 31, c = blockIdx.x * 8 + (threadIdx.x >> 5);
+    double s1, s2;
+    column_sums(partials, n_part, C, c, lane, s1, s2);
+    if (c >= C || lane != 0) return;
+    s1 /= (double)rows;
+    s2 /= (double)rows;
+    const float m = (float)((double)x0[c] + s1);
+    const double vd = s2 - s1 * s1;
+    const float v = (float)(vd > 0.0 ? vd : 0.0);
+    const float is = rsqrtf(v + eps);
+    const float w = weight ? weight[c] : 1.0f, bb = bias ? bias[c] : 0.0f;
+    const float sc = is * w;
+    mean[c] = m;
+    var[c] = v;
+    invstd[c] = is;
+    scale[c] = sc;
+    shift[c] = bb - m * sc;
+    if (running_mean && running_var) {
+        // momentum < 0: cumulative moving average over the batches seen (momentum=None); the caller has counted this one
+        const float mo = momentum >= 0.0f ? momentum : 1.0f / (float)(num_batches ? *num_batches : 1);
+        const float unbiased = v * ((float)rows / (float)(rows > 1 ? rows - 1 : 1));
+        running_mean[c] = running_mean[c] * (1.0f - mo) + m * mo;
+        running_var[c] = running_var[c] * (1.0f - mo) + unbiased * mo;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_coeffs(const float* __restrict__ partials, int n_part, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ weight,
+                                                       int64_t rows, int C, float* a, float* b, float* c_, float* dweight,
+                                                       float* dbias) {
+    const int lane = threadIdx.x & 31, c = blockIdx.x * 8 + (threadIdx.x >> 5);
+    double t1, t2;
+    column_sums(partials, n_part, C, c, lane, t1, t2);
+    if (c >= C || lane != 0) return;
+    const float s1 = (float)t1;                                      // sum dy
+    const float s2 = ((float)t2 - mean[c] * s1) * invstd[c];          // sum dy * xhat
+    const float av = (weight ? weight[c] : 1.0f) * invstd[c];
+    const float bv = -av * invstd[c] * s2 / (float)rows;
+    a[c] = av;
+    b[c] = bv;
+    c_[c] = -av * s1 / (float)rows - bv * mean[c];
+    dweight[c] = s2;
+    dbias[c] = s1;
+}
+
+}  // namespace
+
+extern "C" int ec_bn_finalize(const float* partials, int32_t n_partials, const float* x_row0, int64_t rows, int32_t C,
+                              const float* weight, const float* bias, float eps, float momentum, float* running_mean,
+                              float* running_var, const int64_t* num_batches_tracked, float* mean, float* var, float* invstd,
+                              float* scale, float* shift, void* stream) {
+    if (!partials || !x_row0 || !mean || !var || !invstd || !scale || !shift) return ec::fail(EC_EINVAL, "ec_bn_finalize: null pointer");
+    if (n_partials < 1 || rows < 1 || C < 1 || C > 256) return ec::fail(EC_EINVAL, "ec_bn_finalize: n_partials %d, rows %lld, C %d (<= 256)", n_partials, (long long)rows, C);
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partials, n_partials, x_row0, rows, C, weight, bias,
+                       eps, momentum, running_mean, running_var, num_batches_tracked, mean, var, invstd, scale, shift);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+extern "C" int ec_bn_bwd_coeffs(const float* partials, int32_t n_partials, const float* mean, const float* invstd,
+                                const float* weight, int64_t rows, int32_t C, float* a, float* b, float* c, float* dweight,
+                                float* dbias, void* stream) {
+    if (!partials || !mean || !invstd || !a || !b || !c || !dweight || !dbias) return ec::fail(EC_EINVAL, "ec_bn_bwd_coeffs: null pointer");
+    if (n_partials < 1 || rows < 1 || C < 1 || C > 256) return ec::fail(EC_EINVAL, "ec_bn_bwd_coeffs: n_partials %d, rows %lld, C %d (<= 256)", n_partials, (long long)rows, C);
+    hipLaunchKernelGGL(k_bn_bwd_coeffs, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, partials, n_partials, mean, invstd, weight, rows, C,
+                       a, b, c, dweight, dbias);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}

@@ -152,26 +152,32 @@ class _BnReluDropHipFn(th.autograd.Function):
         return vp, (vp(x), vp(scale), vp(shift), vp(mask), C.c_uint64(seed), C.c_float(p))
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, p):
+    def forward(ctx, x, weight, bias, eps, p, running=None):
+        """running: (running_mean, running_var, num_batches_tracked, momentum or None) of the module, updated in the
+        same launch that finalises the statistics (through raw pointers: autograd does not see the buffers change)"""
         import ctypes as C
 
         from marl_amd import _abi
         x = x.contiguous()
         rows, Cc = x.shape
         stream = C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
         # batch statistics: one streaming pass (ec_bn_col_stats; torch.var_mean's column reduction runs at a third of
-        # the HBM rate), per-block partial sums about the pivot row x[0], added up in float64
+        # the HBM rate), per-block partial sums about the pivot row x[0]; ec_bn_finalize adds them up in float64 and
+        # derives everything per-column in one launch (mean, var, invstd, scale, shift, running statistics)
         n_part = int(min(_BnReluDropHipFn.N_PARTIALS, max(1, rows // 64)))
         partials = th.empty(n_part, 2, Cc, dtype=th.float32, device=x.device)
+        cols = th.empty(5, Cc, dtype=th.float32, device=x.device)
+        mean, var, invstd, scale, shift = cols.unbind(0)
+        rm, rv, nbt, momentum = running if running is not None else (None, None, None, 0.0)
+        if nbt is not None:
+            nbt.data += 1  # (before the launch: momentum=None weighs this batch 1 / count)
         with th.cuda.device(x.device):
-            _abi.check(_abi.lib().ec_bn_col_stats(C.c_void_p(x.data_ptr()), rows, Cc, n_part,
-                                                  C.c_void_p(partials.data_ptr()), stream), "ec_bn_col_stats")
-        s = partials.double().sum(0) / rows
-        mean = (x[0].double() + s[0]).float()
-        var = (s[1] - s[0] * s[0]).clamp_(min=0.0).float()
-        invstd = th.rsqrt(var + eps)
-        scale = (invstd * weight).contiguous()
-        shift = (bias - mean * scale).contiguous()
+            _abi.check(_abi.lib().ec_bn_col_stats(ptr(x), rows, Cc, n_part, ptr(partials), stream), "ec_bn_col_stats")
+            _abi.check(_abi.lib().ec_bn_finalize(ptr(partials), n_part, ptr(x), rows, Cc, ptr(weight), ptr(bias), C.c_float(eps),
+                                                 C.c_float(-1.0 if momentum is None else float(momentum)), ptr(rm), ptr(rv),
+                                                 ptr(nbt), ptr(mean), ptr(var), ptr(invstd), ptr(scale), ptr(shift), stream),
+                       "ec_bn_finalize")
         mask = _explicit_mask(x, p)
         if mask is not None:
             mask = mask.to(device=x.device, dtype=th.uint8).contiguous()
@@ -200,17 +206,15 @@ class _BnReluDropHipFn(th.autograd.Function):
         with th.cuda.device(x.device):
             _abi.check(_abi.lib().ec_bn_relu_dropout_bwd_sums(vp(dout), *head, rows, Cc, n_part, vp(partials), stream),
                        "ec_bn_relu_dropout_bwd_sums")
-            s = partials.sum(0)
-            s1 = s[0]
-            s2 = (s[1] - mean * s1) * invstd             # sum dy * xhat
-            a = weight * invstd
-            b = -a * invstd * s2 / rows
-            c = -a * s1 / rows - b * mean
-            a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
+            # a, b, c of dx = a dy + b x + c, d weight = sum dy xhat, d bias = sum dy: one launch (ec_bn_bwd_coeffs)
+            cols = th.empty(5, Cc, dtype=th.float32, device=x.device)
+            a, b, c, s2, s1 = cols.unbind(0)
+            _abi.check(_abi.lib().ec_bn_bwd_coeffs(vp(partials), n_part, vp(mean), vp(invstd), vp(weight), rows, Cc, vp(a), vp(b),
+                                                   vp(c), vp(s2), vp(s1), stream), "ec_bn_bwd_coeffs")
             dx = th.empty_like(x)
             _abi.check(_abi.lib().ec_bn_relu_dropout_bwd_dx(vp(dout), *head, vp(a), vp(b), vp(c), rows, Cc, vp(dx), stream),
                        "ec_bn_relu_dropout_bwd_dx")
-        return dx, s2, s1, None, None
+        return dx, s2, s1, None, None, None
 
 
 class TallBatchNorm1d(nn.BatchNorm1d):
@@ -233,8 +237,13 @@ class TallBatchNorm1d(nn.BatchNorm1d):
 
     def relu_dropout(self, x, p):
         """dropout(relu(self(x)), p) for a training-mode input, as one autograd node (HIP kernels on the device)"""
-        fn = _BnReluDropHipFn if self.hip_ok(x) else _TallBnReluDropFn
-        y, mean, var = fn.apply(x, self.weight, self.bias, self.eps, float(p))
+        if self.hip_ok(x):
+            running = None
+            if self.track_running_stats:  # updated by the kernel that finalises the statistics
+                running = (self.running_mean, self.running_var, self.num_batches_tracked, self.momentum)
+            y, _, _ = _BnReluDropHipFn.apply(x, self.weight, self.bias, self.eps, float(p), running)
+            return y
+        y, mean, var = _TallBnReluDropFn.apply(x, self.weight, self.bias, self.eps, float(p))
         self._track(x.shape[0], mean, var)
         return y
 
