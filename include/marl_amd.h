@@ -445,6 +445,12 @@ int ec_adam_clip_step(int32_t n_nets, const int32_t* n_tensors, float* const* pa
  *             caller from the sums and the statistics)
  * keep: `mask` [rows, C] u8 when given, else a counter-based Bernoulli(1 - p) draw from (seed, element index) that the
  * backward recomputes instead of reading.  Replaces F.batch_norm / relu / F.dropout and their autograd backward. */
+/* y = x W^T + b for a tall batch (the same layers' forward, and with w transposed by the caller their input gradient):
+ * x [rows, k_in <= 128], w [c_out <= 128, k_in], b [c_out] or NULL, fp32; one read of x, y written in whole 128-byte lines
+ * (rows as the MFMA's M dimension).  Replaces F.linear for these shapes. */
+int ec_linear_fwd(const float* x, const float* w, const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y,
+                  void* stream);
+
 /* Weight and bias gradient of a Linear layer over a tall batch (gail_network.py:97-125, the discriminator's layers on
  * 4.1 M .. 65.5 M rows): dW [c_out, k_in] = dy^T x, db [c_out] = sum_rows dy for dy [rows, c_out], x [rows, k_in] fp32,
  * c_out in {32, 64, 96, 128}, k_in <= 128.  partials [n_partials][c_out * k_in + c_out] <- per-block sums (dW row-major,

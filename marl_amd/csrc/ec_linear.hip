@@ -1,0 +1,124 @@
+// ec_linear.hip — y = x W^T + b for a tall batch: the forward of the GAIL discriminator's Linear layers
+// (rl/policy_gradient_rl/gail/gail_network.py:97-125: 30 / 50 -> 128 -> 64 -> 32 on 4.1 M .. 65.5 M rows).
+//
+// At these shapes a layer is HBM-bound (read [rows, K], write [rows, C]); hipBLASLt runs it at ~3 TB/s.  Here a wave owns
+// 32 rows at a time and the ROWS are the MFMA's M dimension: D[row][out] += A[row][k] B[k][out].  A lane fetches its row's
+// inputs 16 bytes at a time in the order the MFMA walks them (kperm); the weights sit in LDS in the fragment order of
+// ec_mfma.h (the lane index is the output, as there); and the accumulator leaves lane (out j, half h) holding 16 rows of
+// output j -- so every store instruction writes 32 consecutive floats of two rows: whole 128-byte lines.  (The same
+// kernel with outputs as M, as the fused learner kernels have it, stores 16-byte pieces and runs at hipBLASLt's rate.)
+#include "ec_mfma.h"
+
+namespace {
+
+struct LinArgs {
+    const float* x;  // [rows, K]
+    const float* w;  // [C, K]
+    const float* b;  // [C] or NULL
+    int64_t rows;
+    int K, C;
+    float* y;        // [rows, C]
+};
+
+template <int TO, int TI>
+__global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
+    extern __shared__ __align__(16) float lds[];
+    float* s_f = lds;                      // fragments: 16 TI steps x TO tiles x 64 lanes
+    float* s_b = s_f + 16 * TI * TO * 64;  // [32 TO] bias
+    const int K = p.K, C = p.C;
+    stage_frag(s_f, p.w, K, 1, C, K, 16 * TI, TO, true);
+    for (int i = threadIdx.x; i < 32 * TO; i += blockDim.x) s_b[i] = (p.b && i < C) ? p.b[i] : 0.0f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const bool vec = (K & 3) == 0;  // rows are 16-byte aligned
+    const int64_t n_tiles = (p.rows + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += (int64_t)gridDim.x * nw) {
+        const int64_t rowbase = tile * 32, row = rowbase + j;  // as the A operand, lane (j, half) is row j
+        const bool ok = row < p.rows;
+        const float* xr = p.x + (ok ? row : 0) * K;
+        f32x16 acc[TO];
+#pragma unroll
+        for (int to = 0; to < TO; to++) {
+            const float bias = s_b[32 * to + j];
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[to][r] = bias;
+        }
+#pragma unroll
+        for (int T = 0; T < TI; T++) {
+            float4 xa[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int k0 = 32 * T + 8 * q + 4 * half;
+                if (vec) {
+                    xa[q] = (ok && k0 < K) ? *reinterpret_cast<const float4*>(xr + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    xa[q].x = (ok && k0 + 0 < K) ? xr[k0 + 0] : 0.0f;
+                    xa[q].y = (ok && k0 + 1 < K) ? xr[k0 + 1] : 0.0f;
+                    xa[q].z = (ok && k0 + 2 < K) ? xr[k0 + 2] : 0.0f;
+                    xa[q].w = (ok && k0 + 3 < K) ? xr[k0 + 3] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float av[4] = {xa[q].x, xa[q].y, xa[q].z, xa[q].w};
+#pragma unroll
+                for (int to = 0; to < TO; to++) {
+                    const float4 f = *reinterpret_cast<const float4*>(s_f + (((4 * T + q) * TO + to) * 64 + lane) * 4);
+                    const float bv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[to] = MFMA(av[c], bv[c], acc[to]);
+                }
+            }
+        }
+        // register r of lane (out j, half): row 8 (r >> 2) + 4 half + (r & 3) of the tile
+#pragma unroll
+        for (int to = 0; to < TO; to++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int64_t orow = rowbase + 8 * (r >> 2) + 4 * half + (r & 3);
+                if (orow < p.rows && 32 * to + j < C) p.y[orow * C + 32 * to + j] = acc[to][r];
+            }
+    }
+}
+
+template <int TO, int TI>
+int launch_linear(const LinArgs& a, hipStream_t stream) {
+    const size_t lds = sizeof(float) * ((size_t)16 * TI * TO * 64 + 32 * TO);
+    EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_fwd<TO, TI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    const int64_t tiles = (a.rows + 31) / 32;
+    int64_t blocks = (tiles + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL((k_linear_fwd<TO, TI>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
+}
+
+template <int TO>
+int launch_linear_ti(const LinArgs& a, int TI, hipStream_t stream) {
+    switch (TI) {
+        case 1: return launch_linear<TO, 1>(a, stream);
+        case 2: return launch_linear<TO, 2>(a, stream);
+        case 3: return launch_linear<TO, 3>(a, stream);
+        default: return launch_linear<TO, 4>(a, stream);
+    }
+}
+
+}  // namespace
+
+extern "C" int ec_linear_fwd(const float* x, const float* w, const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y,
+                             void* stream) {
+    if (rows == 0) return EC_OK;
+    if (!x || !w || !y) return ec::fail(EC_EINVAL, "ec_linear_fwd: null pointer");
+    if (rows < 0 || k_in < 1 || k_in > 128 || c_out < 1 || c_out > 128)
+        return ec::fail(EC_EINVAL, "ec_linear_fwd: rows %lld, k_in %d, c_out %d (1..128 each)", (long long)rows, k_in, c_out);
+    const LinArgs a{x, w, b, rows, k_in, c_out, y};
+    const int TI = (k_in + 31) / 32;
+    switch ((c_out + 31) / 32) {
+        case 1: return launch_linear_ti<1>(a, TI, (hipStream_t)stream);
+        case 2: return launch_linear_ti<2>(a, TI, (hipStream_t)stream);
+        case 3: return launch_linear_ti<3>(a, TI, (hipStream_t)stream);
+        default: return launch_linear_ti<4>(a, TI, (hipStream_t)stream);
+    }
+}

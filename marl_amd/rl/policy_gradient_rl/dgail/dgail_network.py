@@ -48,6 +48,8 @@ class _SplitKLinearFn(th.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
+        if linear_device.fwd_ok(x, w):  # (inside a Function's forward grad mode is off)
+            return linear_device.fwd(x, w, b)
         return F.linear(x, w, b)
 
     @staticmethod
@@ -55,7 +57,12 @@ class _SplitKLinearFn(th.autograd.Function):
         x, w = ctx.saved_tensors
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _TallMatmulFn.apply(gy, w) if th.is_grad_enabled() else gy @ w
+            if th.is_grad_enabled():
+                gx = _TallMatmulFn.apply(gy, w)
+            elif linear_device.fwd_ok(gy, w.t()):
+                gx = linear_device.fwd(gy, w.t())     # gy @ w = gy (w^T)^T: the same kernel on the transposed weight
+            else:
+                gx = gy @ w
         if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and linear_device.wgrad_ok(gy, x):
             # one pass over gy and x with the row index as the MFMA's K dimension (ec_linear_wgrad)
             gw, gb = linear_device.wgrad(gy, x)
@@ -80,8 +87,11 @@ class SplitKLinear(nn.Linear):
     MIN_ROWS = 8192
 
     def forward(self, x):
-        if x.dim() == 2 and x.shape[0] >= self.MIN_ROWS and th.is_grad_enabled():
-            return _SplitKLinearFn.apply(x, self.weight, self.bias)
+        if x.dim() == 2 and x.shape[0] >= self.MIN_ROWS:
+            if th.is_grad_enabled():
+                return _SplitKLinearFn.apply(x, self.weight, self.bias)
+            if linear_device.fwd_ok(x, self.weight):  # no-grad evaluations (GAIL's reward pass)
+                return linear_device.fwd(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)
 
 

@@ -1,4 +1,5 @@
-"""Host side of ec_linear_wgrad (include/marl_amd.h): the weight / bias gradient of a Linear layer over a tall batch."""
+"""Host side of ec_linear_wgrad / ec_linear_fwd (include/marl_amd.h): the weight / bias gradient and the forward (or
+input gradient) of a Linear layer over a tall batch."""
 import ctypes as C
 
 import torch as th
@@ -27,3 +28,23 @@ def wgrad(gy, x):
                                               C.c_void_p(th.cuda.current_stream(gy.device).cuda_stream)), "ec_linear_wgrad")
     s = partials.sum(0)
     return s[:c_out * k_in].view(c_out, k_in), s[c_out * k_in:]
+
+
+def fwd_ok(x, w):
+    """shapes for which ec_linear_fwd beats hipBLASLt (measured, tools/bench_linear.py): up to 64 inputs; with 128 the
+    row-per-lane reads lose"""
+    return (x.is_cuda and w.is_cuda and x.dtype == th.float32 and w.dtype == th.float32 and x.dim() == 2 and w.dim() == 2
+            and x.shape[1] == w.shape[1] and 1 <= x.shape[1] <= 64 and 1 <= w.shape[0] <= 128 and not th.is_grad_enabled())
+
+
+def fwd(x, w, b=None):
+    """x @ w.t() + b for x [rows, k_in], w [c_out, k_in] (ec_linear_fwd)"""
+    x, w = x.contiguous(), w.contiguous()
+    rows, k_in = x.shape
+    c_out = w.shape[0]
+    y = th.empty(rows, c_out, dtype=th.float32, device=x.device)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    with th.cuda.device(x.device):
+        _abi.check(_abi.lib().ec_linear_fwd(ptr(x), ptr(w), ptr(b.contiguous() if b is not None else None), rows, k_in, c_out,
+                                            ptr(y), C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)), "ec_linear_fwd")
+    return y

@@ -136,3 +136,36 @@ def test_linear_wgrad_matches_float64(rows, c_out, k_in):
         assert th.allclose(xa.grad, xb.grad, rtol=1e-5, atol=1e-6)
         for pa, pb in zip(a.parameters(), b.parameters()):
             assert float((pa.grad - pb.grad).abs().max()) <= 1e-4 * float(pb.grad.abs().max() + 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,k_in,c_out", [(1, 1, 1), (33, 30, 128), (100003, 64, 32), (5000, 9, 5), (70001, 50, 96),
+                                             (8192, 32, 64)])
+def test_linear_fwd_matches_float64(rows, k_in, c_out):
+    """ec_linear_fwd (y = x W^T + b, rows as the MFMA's M dimension) against float64: ragged row counts, input widths that
+    are not multiples of 4 or 32, output widths that are not multiples of 32, with and without bias; and SplitKLinear
+    (forward, input gradient, weight gradient on the HIP kernels) against nn.Linear end to end."""
+    import torch as th
+    from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import SplitKLinear
+    from marl_amd.utils import linear_device
+    gen = th.Generator().manual_seed(rows + k_in + c_out)
+    x = th.randn(rows, k_in, generator=gen).cuda()
+    w, b = (th.randn(c_out, k_in, generator=gen) * 0.3).cuda(), th.randn(c_out, generator=gen).cuda()
+    with th.no_grad():
+        assert linear_device.fwd_ok(x, w)
+        for bias in (b, None):
+            got = linear_device.fwd(x, w, bias)
+            want = x.double() @ w.double().t() + (bias.double() if bias is not None else 0.0)
+            assert float((got.double() - want).abs().max()) <= 2e-6 * float(want.abs().max() + 1)
+    if rows >= SplitKLinear.MIN_ROWS and c_out in (32, 64, 96, 128):
+        a, ref = SplitKLinear(k_in, c_out).cuda(), th.nn.Linear(k_in, c_out).cuda()
+        ref.load_state_dict(a.state_dict())
+        g = th.randn(rows, c_out, generator=gen).cuda()
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb = a(xa), ref(xb)
+        assert th.allclose(ya, yb, rtol=1e-5, atol=1e-5)
+        (ya * g).sum().backward()
+        (yb * g).sum().backward()
+        assert th.allclose(xa.grad, xb.grad, rtol=1e-5, atol=1e-5)
+        for pa, pb in zip(a.parameters(), ref.parameters()):
+            assert float((pa.grad - pb.grad).abs().max()) <= 1e-4 * float(pb.grad.abs().max() + 1)

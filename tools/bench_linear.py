@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""ec_linear_fwd against F.linear at the GAIL discriminator's forward and input-gradient shapes; checks the values too."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch as th  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from marl_amd import _abi  # noqa: E402
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4096000
+L = _abi.lib()
+vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
+
+
+def timed(fn, reps=10):
+    for _ in range(2):
+        fn()
+    th.cuda.synchronize()
+    a, b = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    th.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e-3
+
+
+th.set_grad_enabled(False)
+for k_in, c_out in ((30, 128), (128, 64), (64, 32), (32, 64), (64, 128), (128, 30)):
+    x = th.randn(rows, k_in, device="cuda")
+    w, b = th.randn(c_out, k_in, device="cuda") * 0.2, th.randn(c_out, device="cuda")
+    y = th.empty(rows, c_out, device="cuda")
+    t0 = timed(lambda: _abi.check(L.ec_linear_fwd(vp(x), vp(w), vp(b), rows, k_in, c_out, vp(y), stream), "ec_linear_fwd"))
+    want = F.linear(x, w, b)
+    err = float((y - want).abs().max())
+    t2 = timed(lambda: F.linear(x, w, b))
+    print("rows %d  %3d -> %3d  ec_linear_fwd %7.1f us (%.2f TB/s)   F.linear %7.1f us   max |diff| %.2e" % (
+        rows, k_in, c_out, t0 * 1e6, rows * (k_in + c_out) * 4 / t0 / 1e12, t2 * 1e6, err))
