@@ -9,7 +9,7 @@ import re
 import sys
 
 out_dir, mode = sys.argv[1], sys.argv[2]
-want = {"rollout": "k_step<4, 4, true>", "step": "k_step<4, 4, false>", "mlp": "k_rollout_mlp<4, 4>"}[mode]
+want = {"rollout": "k_step<4, 4, true>", "step": "k_step<4, 4, false>", "mlp": "k_rollout_mlp<4, 4, false, 1>"}[mode]
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = []
