@@ -450,6 +450,12 @@ int ec_adam_clip_step(int32_t n_nets, const int32_t* n_tensors, float* const* pa
  * (rows as the MFMA's M dimension).  Replaces F.linear for these shapes. */
 int ec_linear_fwd(const float* x, const float* w, const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y,
                   void* stream);
+/* The same with the previous layer's BatchNorm -> ReLU -> Dropout tail applied on the way in:
+ * y = (relu(x * scale + shift) * keep / (1 - p)) W^T + b, keep = ec_bn_relu_dropout_fwd's counter-based draw for `seed`
+ * (element index row * k_in + col), 0 <= p < 1.  The activated [rows, k_in] tensor is never written: for passes that
+ * keep nothing for a backward (gail_agent.py:165-167, the reward pass under no_grad with the network in training mode). */
+int ec_linear_fwd_bn(const float* x, const float* scale, const float* shift, uint64_t seed, float p, const float* w,
+                     const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y, void* stream);
 
 /* Weight and bias gradient of a Linear layer over a tall batch (gail_network.py:97-125, the discriminator's layers on
  * 4.1 M .. 65.5 M rows): dW [c_out, k_in] = dy^T x, db [c_out] = sum_rows dy for dy [rows, c_out], x [rows, k_in] fp32,

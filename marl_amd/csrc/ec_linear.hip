@@ -18,16 +18,32 @@ struct LinArgs {
     int64_t rows;
     int K, C;
     float* y;        // [rows, C]
+    // BN: the input is the previous layer's pre-BatchNorm output; a = relu(x * scale + shift) * keep / (1 - p) is formed
+    // in registers on the way to the MFMA (csrc/ec_bn.hip's forward, same arithmetic and the same keep_draw)
+    const float* scale;  // [K]
+    const float* shift;  // [K]
+    uint64_t seed;
+    uint32_t thr24;
+    float inv_keep;
 };
 
-template <int TO, int TI>
+// (the keep flags are ec_bn.hip's keep_draw(seed, row * K + col), restated in the kernel with the per-row work hoisted: the
+// two must stay the same function -- tests compare the fused layer with the two-step one bit for bit)
+template <int TO, int TI, bool BN>
 __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
     extern __shared__ __align__(16) float lds[];
     float* s_f = lds;                      // fragments: 16 TI steps x TO tiles x 64 lanes
     float* s_b = s_f + 16 * TI * TO * 64;  // [32 TO] bias
+    float* s_sc = s_b + 32 * TO;           // BN: [32 TI] scale, [32 TI] shift
+    float* s_sh = s_sc + 32 * TI;
     const int K = p.K, C = p.C;
     stage_frag(s_f, p.w, K, 1, C, K, 16 * TI, TO, true);
     for (int i = threadIdx.x; i < 32 * TO; i += blockDim.x) s_b[i] = (p.b && i < C) ? p.b[i] : 0.0f;
+    if (BN)
+        for (int i = threadIdx.x; i < 32 * TI; i += blockDim.x) {
+            s_sc[i] = i < K ? p.scale[i] : 0.0f;
+            s_sh[i] = i < K ? p.shift[i] : 0.0f;
+        }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int j = lane & 31, half = lane >> 5;
@@ -37,6 +53,18 @@ __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
         const int64_t rowbase = tile * 32, row = rowbase + j;  // as the A operand, lane (j, half) is row j
         const bool ok = row < p.rows;
         const float* xr = p.x + (ok ? row : 0) * K;
+        // BN: keep_draw(seed, row * K + k) with the per-row part of the hash taken out of the element loop.  The index's
+        // low word times the first constant is linear in k (mod 2^32), and its high word takes one of two values per row
+        // (k < 128 carries at most once): two multiplies per element are left, the finaliser's.
+        uint32_t kd_lo = 0, kd_mul = 0, kd_hi0 = 0, kd_hi1 = 0;
+        if (BN) {
+            const uint64_t base = (uint64_t)(ok ? row : 0) * (uint64_t)K + (uint64_t)(4 * half);
+            kd_lo = (uint32_t)base;
+            kd_mul = kd_lo * 0x9e3779b1u;
+            const uint32_t hi = (uint32_t)(base >> 32) + (uint32_t)(p.seed >> 32);
+            kd_hi0 = hi * 0x85ebca77u;
+            kd_hi1 = (hi + 1u) * 0x85ebca77u;
+        }
         f32x16 acc[TO];
 #pragma unroll
         for (int to = 0; to < TO; to++) {
@@ -57,6 +85,31 @@ __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
                     xa[q].y = (ok && k0 + 1 < K) ? xr[k0 + 1] : 0.0f;
                     xa[q].z = (ok && k0 + 2 < K) ? xr[k0 + 2] : 0.0f;
                     xa[q].w = (ok && k0 + 3 < K) ? xr[k0 + 3] : 0.0f;
+                }
+            }
+            if (BN) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int k0 = 32 * T + 8 * q + 4 * half;
+                    const float4 sc = *reinterpret_cast<const float4*>(s_sc + k0), sh = *reinterpret_cast<const float4*>(s_sh + k0);
+                    const float xv[4] = {xa[q].x, xa[q].y, xa[q].z, xa[q].w}, scv[4] = {sc.x, sc.y, sc.z, sc.w},
+                                shv[4] = {sh.x, sh.y, sh.z, sh.w};
+                    float o[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const float yv = xv[c] * scv[c] + shv[c];
+                        const uint32_t off = (uint32_t)(32 * T + 8 * q + c);   // (compile-time; 4 * half is in the base)
+                        uint32_t h = (kd_mul + off * 0x9e3779b1u) ^ (uint32_t)p.seed;
+                        h ^= (kd_lo + off < kd_lo) ? kd_hi1 : kd_hi0;
+                        h ^= h >> 16;
+                        h *= 0x85ebca6bu;
+                        h ^= h >> 13;
+                        h *= 0xc2b2ae35u;
+                        h ^= h >> 16;
+                        const bool keep = ok && k0 + c < K && (h >> 8) >= p.thr24;
+                        o[c] = (keep && yv > 0.0f) ? yv * p.inv_keep : 0.0f;
+                    }
+                    xa[q] = make_float4(o[0], o[1], o[2], o[3]);
                 }
             }
 #pragma unroll
@@ -82,26 +135,37 @@ __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
     }
 }
 
-template <int TO, int TI>
+template <int TO, int TI, bool BN>
 int launch_linear(const LinArgs& a, hipStream_t stream) {
-    const size_t lds = sizeof(float) * ((size_t)16 * TI * TO * 64 + 32 * TO);
-    EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_fwd<TO, TI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const size_t lds = sizeof(float) * ((size_t)16 * TI * TO * 64 + 32 * TO + 64 * TI);
+    EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_fwd<TO, TI, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
     const int64_t tiles = (a.rows + 31) / 32;
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL((k_linear_fwd<TO, TI>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((k_linear_fwd<TO, TI, BN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
     EC_HIP(hipGetLastError());
     return EC_OK;
 }
 
-template <int TO>
+template <int TO, bool BN>
 int launch_linear_ti(const LinArgs& a, int TI, hipStream_t stream) {
     switch (TI) {
-        case 1: return launch_linear<TO, 1>(a, stream);
-        case 2: return launch_linear<TO, 2>(a, stream);
-        case 3: return launch_linear<TO, 3>(a, stream);
-        default: return launch_linear<TO, 4>(a, stream);
+        case 1: return launch_linear<TO, 1, BN>(a, stream);
+        case 2: return launch_linear<TO, 2, BN>(a, stream);
+        case 3: return launch_linear<TO, 3, BN>(a, stream);
+        default: return launch_linear<TO, 4, BN>(a, stream);
+    }
+}
+
+template <bool BN>
+int launch_linear_to(const LinArgs& a, hipStream_t stream) {
+    const int TI = (a.K + 31) / 32;
+    switch ((a.C + 31) / 32) {
+        case 1: return launch_linear_ti<1, BN>(a, TI, stream);
+        case 2: return launch_linear_ti<2, BN>(a, TI, stream);
+        case 3: return launch_linear_ti<3, BN>(a, TI, stream);
+        default: return launch_linear_ti<4, BN>(a, TI, stream);
     }
 }
 
@@ -113,12 +177,20 @@ extern "C" int ec_linear_fwd(const float* x, const float* w, const float* b, int
     if (!x || !w || !y) return ec::fail(EC_EINVAL, "ec_linear_fwd: null pointer");
     if (rows < 0 || k_in < 1 || k_in > 128 || c_out < 1 || c_out > 128)
         return ec::fail(EC_EINVAL, "ec_linear_fwd: rows %lld, k_in %d, c_out %d (1..128 each)", (long long)rows, k_in, c_out);
-    const LinArgs a{x, w, b, rows, k_in, c_out, y};
-    const int TI = (k_in + 31) / 32;
-    switch ((c_out + 31) / 32) {
-        case 1: return launch_linear_ti<1>(a, TI, (hipStream_t)stream);
-        case 2: return launch_linear_ti<2>(a, TI, (hipStream_t)stream);
-        case 3: return launch_linear_ti<3>(a, TI, (hipStream_t)stream);
-        default: return launch_linear_ti<4>(a, TI, (hipStream_t)stream);
-    }
+    const LinArgs a{x, w, b, rows, k_in, c_out, y, nullptr, nullptr, 0, 0, 1.0f};
+    return launch_linear_to<false>(a, (hipStream_t)stream);
+}
+
+// y = dropout(relu(x * scale + shift), p) W^T + b: the BatchNorm -> ReLU -> Dropout tail of the previous layer (scale, shift
+// from ec_bn_finalize; the keep flags are ec_bn_relu_dropout_fwd's draws for the same seed) applied on the way in, so the
+// activated [rows, k_in] tensor is never written.  For passes that keep nothing for a backward (GAIL's reward pass).
+extern "C" int ec_linear_fwd_bn(const float* x, const float* scale, const float* shift, uint64_t seed, float p, const float* w,
+                                const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y, void* stream) {
+    if (rows == 0) return EC_OK;
+    if (!x || !scale || !shift || !w || !y) return ec::fail(EC_EINVAL, "ec_linear_fwd_bn: null pointer");
+    if (rows < 0 || k_in < 1 || k_in > 128 || c_out < 1 || c_out > 128)
+        return ec::fail(EC_EINVAL, "ec_linear_fwd_bn: rows %lld, k_in %d, c_out %d (1..128 each)", (long long)rows, k_in, c_out);
+    if (!(p >= 0.0f && p < 1.0f)) return ec::fail(EC_EINVAL, "ec_linear_fwd_bn: dropout p %g outside [0, 1)", (double)p);
+    const LinArgs a{x, w, b, rows, k_in, c_out, y, scale, shift, seed, (uint32_t)((double)p * 16777216.0), 1.0f / (1.0f - p)};
+    return launch_linear_to<true>(a, (hipStream_t)stream);
 }

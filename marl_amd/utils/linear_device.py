@@ -48,3 +48,25 @@ def fwd(x, w, b=None):
         _abi.check(_abi.lib().ec_linear_fwd(ptr(x), ptr(w), ptr(b.contiguous() if b is not None else None), rows, k_in, c_out,
                                             ptr(y), C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)), "ec_linear_fwd")
     return y
+
+
+def fwd_bn_ok(x, w):
+    """shapes ec_linear_fwd_bn takes (any k_in <= 128: against a separate tail kernel plus a GEMM it wins at 128 too)"""
+    return (x.is_cuda and w.is_cuda and x.dtype == th.float32 and w.dtype == th.float32 and x.dim() == 2 and w.dim() == 2
+            and x.shape[1] == w.shape[1] and 1 <= x.shape[1] <= 128 and 1 <= w.shape[0] <= 128 and not th.is_grad_enabled())
+
+
+def fwd_bn(x, scale, shift, seed, p, w, b=None):
+    """dropout(relu(x * scale + shift), p) @ w.t() + b with the keep flags of ec_bn_relu_dropout_fwd for `seed`
+    (ec_linear_fwd_bn): nothing of the activated tensor is written"""
+    x, w = x.contiguous(), w.contiguous()
+    rows, k_in = x.shape
+    c_out = w.shape[0]
+    y = th.empty(rows, c_out, dtype=th.float32, device=x.device)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    with th.cuda.device(x.device):
+        _abi.check(_abi.lib().ec_linear_fwd_bn(ptr(x), ptr(scale.contiguous()), ptr(shift.contiguous()), C.c_uint64(seed),
+                                               C.c_float(p), ptr(w), ptr(b.contiguous() if b is not None else None), rows, k_in,
+                                               c_out, ptr(y), C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)),
+                   "ec_linear_fwd_bn")
+    return y

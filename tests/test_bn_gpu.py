@@ -169,3 +169,92 @@ def test_linear_fwd_matches_float64(rows, k_in, c_out):
         assert th.allclose(xa.grad, xb.grad, rtol=1e-5, atol=1e-5)
         for pa, pb in zip(a.parameters(), ref.parameters()):
             assert float((pa.grad - pb.grad).abs().max()) <= 1e-4 * float(pb.grad.abs().max() + 1)
+
+
+@pytest.mark.parametrize("rows,k_in,c_out,p", [(70001, 128, 64, 0.3), (4097, 64, 32, 0.3), (100003, 32, 1, 0.2),
+                                               (33, 128, 128, 0.0), (2, 36, 40, 0.5)])
+def test_linear_fwd_bn_equals_tail_then_linear(rows, k_in, c_out, p):
+    """ec_linear_fwd_bn (the BatchNorm -> ReLU -> Dropout tail applied inside the next Linear's kernel) against the two
+    kernels it replaces, ec_bn_relu_dropout_fwd then ec_linear_fwd, for the same seed: bit for bit (same arithmetic, same
+    keep_draw, same MFMA order); and against float64 on the two-step's activated tensor."""
+    import ctypes as C
+    from marl_amd import _abi
+    from marl_amd.utils import linear_device
+    gen = th.Generator().manual_seed(rows + k_in + c_out)
+    x = th.randn(rows, k_in, generator=gen).cuda()
+    scale, shift = (th.rand(k_in, generator=gen) + 0.5).cuda(), (th.randn(k_in, generator=gen) * 0.5).cuda()
+    w, b = (th.randn(c_out, k_in, generator=gen) * 0.3).cuda(), th.randn(c_out, generator=gen).cuda()
+    seed = 0x1234567890abcdef + rows
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
+    with th.no_grad():
+        assert linear_device.fwd_bn_ok(x, w)
+        if k_in % 4 == 0 and 256 % (k_in // 4) == 0:
+            act = th.empty_like(x)
+            _abi.check(_abi.lib().ec_bn_relu_dropout_fwd(vp(x), vp(scale), vp(shift), C.c_void_p(0), C.c_uint64(seed), C.c_float(p),
+                                                         rows, k_in, vp(act), stream), "ec_bn_relu_dropout_fwd")
+            kept = float((act != 0).float().mean())
+            want_kept = float(((x * scale + shift) > 0).float().mean()) * (1 - p)
+            assert abs(kept - want_kept) < 0.02 + 2.0 / (rows * k_in) ** 0.5
+        else:   # a width the tail kernel's thread mapping does not take: its formula in torch, keep flags off the fused output
+            act = None
+        for bias in (b, None):
+            got = linear_device.fwd_bn(x, scale, shift, seed, p, w, bias)
+            if act is not None:
+                two_step = linear_device.fwd(act, w, bias)
+                assert th.equal(got, two_step)
+                want = act.double() @ w.double().t() + (bias.double() if bias is not None else 0.0)
+                assert float((got.double() - want).abs().max()) <= 2e-6 * float(want.abs().max() + 1)
+        if act is None:   # identity weight block reads the activated values back out of the fused kernel
+            eye = th.eye(k_in, device="cuda")
+            a_out = th.cat([linear_device.fwd_bn(x, scale, shift, seed, p, eye[i:i + 32].contiguous()) for i in range(0, k_in, 32)], 1)
+            y = x * scale + shift
+            full = th.where(y > 0, y * (1.0 / (1.0 - p)), th.zeros_like(y))
+            assert bool(((a_out == 0) | (a_out == full)).all())
+            assert abs(float((a_out != 0).float().mean()) - float((y > 0).float().mean()) * (1 - p)) < 0.25
+    # argument checks
+    lib = _abi.lib()
+    assert lib.ec_linear_fwd_bn(vp(x), vp(scale), vp(shift), C.c_uint64(1), C.c_float(1.0), vp(w), vp(b), rows, k_in, c_out, vp(x), stream) != 0
+    assert lib.ec_linear_fwd_bn(vp(x), vp(scale), vp(shift), C.c_uint64(1), C.c_float(0.1), vp(w), vp(b), rows, 129, c_out, vp(x), stream) != 0
+    assert lib.ec_linear_fwd_bn(vp(x), C.c_void_p(0), vp(shift), C.c_uint64(1), C.c_float(0.1), vp(w), vp(b), rows, k_in, c_out, vp(x), stream) != 0
+
+
+@pytest.mark.parametrize("rows,n_agents,n_actions", [(50000, 10, 11), (20000, 40, 41)])
+def test_discriminator_no_grad_pass_fused_tails(rows, n_agents, n_actions, monkeypatch):
+    """Discriminator.forward_rows under no_grad in training mode (GAIL's reward pass, gail_agent.py:165-167) folds every
+    layer's tail into the next Linear (ec_linear_fwd_bn).  Same torch seed => the same dropout draws as the layer-by-layer
+    path: logits equal to fp32 rounding (the 128-wide GEMM of the layer-by-layer path is hipBLASLt's), running statistics
+    and batch counters advanced alike."""
+    import copy
+    from types import SimpleNamespace
+    import marl_amd.rl.policy_gradient_rl.gail.gail_network as gn
+    args = SimpleNamespace(obs_shape=9, n_agents=n_agents, n_actions=n_actions, hidden_dim=64, activate_fun="relu")
+    th.manual_seed(3)
+    a = gn.Discriminator(args).cuda()
+    with th.no_grad():
+        for m in a.modules():
+            if isinstance(m, th.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    b = copy.deepcopy(a)
+    x = th.randn(rows, 9 + n_agents + n_actions, device="cuda")
+    with th.no_grad():
+        assert a._fused_tails_ok(x)
+        th.manual_seed(11)
+        ya = a.forward_rows(x)
+        monkeypatch.setattr(gn.Discriminator, "_fused_tails_ok", lambda self, x_: False)
+        th.manual_seed(11)
+        yb = b.forward_rows(x)
+    assert ya.shape == yb.shape == (rows, 1)
+    assert float((ya - yb).abs().max()) <= 1e-4 * float(yb.abs().max() + 1)
+    for (na, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert th.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-6), na
+    assert int(a.bn1.num_batches_tracked) == 1
+    # with grad enabled, or with a test's mask hook in place, the layer-by-layer path runs
+    monkeypatch.undo()
+    assert not a._fused_tails_ok(x.requires_grad_(True)) or not th.is_grad_enabled()
+    with th.enable_grad():
+        assert not a._fused_tails_ok(x)
+    monkeypatch.setattr(gn, "_explicit_mask", lambda x_, p_: None)
+    with th.no_grad():
+        assert not a._fused_tails_ok(x)
