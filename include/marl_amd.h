@@ -454,6 +454,12 @@ int ec_linear_fwd(const float* x, const float* w, const float* b, int64_t rows, 
  * y = (relu(x * scale + shift) * keep / (1 - p)) W^T + b, keep = ec_bn_relu_dropout_fwd's counter-based draw for `seed`
  * (element index row * k_in + col), 0 <= p < 1.  The activated [rows, k_in] tensor is never written: for passes that
  * keep nothing for a backward (gail_agent.py:165-167, the reward pass under no_grad with the network in training mode). */
+/* The GAIL discriminator's input rows (gail_agent.py:131-141, gail_network.py:127-131: obs with the agent's one-hot id,
+ * concatenated with the one-hot action): out [rows, obs_dim + n_agents + n_actions] fp32 from obs [rows, obs_dim] fp32 and
+ * actions [rows] int64, rows in [.., agent] order (row r belongs to agent r % n_agents).  One write of the rows instead of
+ * two torch.cat passes and a one_hot. */
+int ec_disc_rows(const float* obs, const int64_t* actions, int64_t rows, int32_t obs_dim, int32_t n_agents, int32_t n_actions,
+                 float* out, void* stream);
 int ec_linear_fwd_bn(const float* x, const float* scale, const float* shift, uint64_t seed, float p, const float* w,
                      const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y, void* stream);
 

@@ -135,6 +135,25 @@ __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
     }
 }
 
+// The discriminator's input rows (obs | agent one-hot | action one-hot), gail_agent.py:131-141: a block writes 256
+// consecutive rows, its threads walking the output elements in order (whole lines per store instruction).
+__global__ void __launch_bounds__(256) k_disc_rows(const float* __restrict__ obs, const int64_t* __restrict__ actions, int64_t rows,
+                                                   int O, int N, int A, float* __restrict__ out) {
+    const int W = O + N + A;
+    for (int64_t r0 = (int64_t)blockIdx.x * 256; r0 < rows; r0 += (int64_t)gridDim.x * 256) {
+        const int n = (int)(rows - r0 < 256 ? rows - r0 : 256);
+        const int first_agent = (int)(r0 % N);
+        for (int j = threadIdx.x; j < n * W; j += 256) {
+            const int r = j / W, c = j - r * W;
+            float v;
+            if (c < O) v = obs[(r0 + r) * O + c];
+            else if (c < O + N) v = (c - O == (first_agent + r) % N) ? 1.0f : 0.0f;
+            else v = ((int64_t)(c - O - N) == actions[r0 + r]) ? 1.0f : 0.0f;
+            out[r0 * W + j] = v;
+        }
+    }
+}
+
 template <int TO, int TI, bool BN>
 int launch_linear(const LinArgs& a, hipStream_t stream) {
     const size_t lds = sizeof(float) * ((size_t)16 * TI * TO * 64 + 32 * TO + 64 * TI);
@@ -193,4 +212,21 @@ extern "C" int ec_linear_fwd_bn(const float* x, const float* scale, const float*
     if (!(p >= 0.0f && p < 1.0f)) return ec::fail(EC_EINVAL, "ec_linear_fwd_bn: dropout p %g outside [0, 1)", (double)p);
     const LinArgs a{x, w, b, rows, k_in, c_out, y, scale, shift, seed, (uint32_t)((double)p * 16777216.0), 1.0f / (1.0f - p)};
     return launch_linear_to<true>(a, (hipStream_t)stream);
+}
+
+// out [rows, obs_dim + n_agents + n_actions] = (obs row | one-hot of row % n_agents | one-hot of the row's action): the
+// input of the GAIL discriminator for rows in [.., agent] order (an action outside [0, n_actions) sets nothing).
+extern "C" int ec_disc_rows(const float* obs, const int64_t* actions, int64_t rows, int32_t obs_dim, int32_t n_agents,
+                            int32_t n_actions, float* out, void* stream) {
+    if (rows == 0) return EC_OK;
+    if (!obs || !actions || !out) return ec::fail(EC_EINVAL, "ec_disc_rows: null pointer");
+    if (rows < 0 || obs_dim < 1 || n_agents < 1 || n_actions < 1 || obs_dim + n_agents + n_actions > 4096)
+        return ec::fail(EC_EINVAL, "ec_disc_rows: rows %lld, obs_dim %d, n_agents %d, n_actions %d", (long long)rows, obs_dim,
+                        n_agents, n_actions);
+    int64_t blocks = (rows + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_disc_rows, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, obs, actions, rows, obs_dim, n_agents,
+                       n_actions, out);
+    EC_HIP(hipGetLastError());
+    return EC_OK;
 }

@@ -20,7 +20,7 @@ from torch.optim import Adam
 from marl_amd.buffer.expert_transitions import ExpertTransitions
 from marl_amd.buffer.ppo_expert_buffer import PPOExpertBuffer
 from marl_amd.rl.policy_gradient_rl.gail.gail_network import Actor, Critic, Discriminator
-from marl_amd.utils import mlp_device, optim_device, ppo_device
+from marl_amd.utils import linear_device, mlp_device, optim_device, ppo_device
 from marl_amd.utils.action_selectors import greedy_selector, soft_selector
 from marl_amd.utils.advantage_utils import get_gae
 from marl_amd.utils.dist_utils import (all_reduce_grads_, all_reduce_sum_, broadcast_params_, global_mean_std,
@@ -124,16 +124,20 @@ class GAILAgent:
         else:
             self.bc_loss_weight = max(self.min_bc_weight, self.bc_loss_weight * self.bc_decay_rate)
 
-    def _discriminator_step(self, obs_id, actions):
-        """gail_agent.py:131-172: returns the GAIL rewards [B,T,N,1] of the rollout."""
+    def _discriminator_step(self, obs, actions):
+        """gail_agent.py:131-172: returns the GAIL rewards [B,T,N,1] of the rollout (obs without the agent ids)."""
         a = self.args
-        B, T, N = obs_id.shape[0], obs_id.shape[1], obs_id.shape[2]
-        onehot = F.one_hot(actions.squeeze(-1), num_classes=a.n_actions).float()
+        B, T, N = obs.shape[0], obs.shape[1], obs.shape[2]
         e_obs, e_act = self.expert_transitions.sample_transitions(64)
         expert_logits = self.discriminator(self._with_ids(e_obs), F.one_hot(e_act, num_classes=a.n_actions).float())
         # the agent rows (obs | id | one-hot action), built once for the training pass and the reward pass below
-        agent_rows = self.discriminator.rows(obs_id.reshape(-1, obs_id.size(-1)), onehot.reshape(-1, onehot.size(-1)))
-        del onehot
+        if obs.is_cuda and obs.dtype == th.float32 and actions.dtype == th.int64:
+            agent_rows = linear_device.disc_rows(obs, actions, N, a.n_actions)      # one write (ec_disc_rows)
+        else:
+            obs_id = self._with_ids(obs)
+            onehot = F.one_hot(actions.squeeze(-1), num_classes=a.n_actions).float()
+            agent_rows = self.discriminator.rows(obs_id.reshape(-1, obs_id.size(-1)), onehot.reshape(-1, onehot.size(-1)))
+            del obs_id, onehot
         agent_logits = self.discriminator.forward_rows(agent_rows)
         bce = nn.BCEWithLogitsLoss()
         loss = bce(agent_logits.reshape(-1, 1), th.ones_like(agent_logits.reshape(-1, 1))) + \
@@ -198,12 +202,11 @@ class GAILAgent:
     def train(self):
         a = self.args
         obs, avail_actions, actions, rewards, masks, next_obs = self.buffer.sample()
-        obs_id = self._with_ids(obs)
         if self.expert_transitions.global_len() >= 10:  # the ranks' minimum: all of them step, or none
-            rewards = self._discriminator_step(obs_id, actions)
+            rewards = self._discriminator_step(obs, actions)
         if self._fg_actor is not None:
-            del obs_id
             return self._train_fused(obs, avail_actions, actions, rewards, masks, next_obs)
+        obs_id = self._with_ids(obs)
         next_obs_id = self._with_ids(next_obs)
         if a.normalize_rewards:
             mean, std = global_mean_std(rewards)

@@ -70,3 +70,19 @@ def fwd_bn(x, scale, shift, seed, p, w, b=None):
                                                c_out, ptr(y), C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)),
                    "ec_linear_fwd_bn")
     return y
+
+
+def disc_rows(obs, actions, n_agents, n_actions):
+    """(obs | one-hot agent id | one-hot action) rows [rows, O + N + A] of obs [..., N, O] and actions [..., N(, 1)] on the
+    device (ec_disc_rows): what Discriminator.rows(cat([obs, eye]), one_hot(actions)) builds, in one write"""
+    O = obs.shape[-1]
+    obs = obs.reshape(-1, O).contiguous()
+    actions = actions.reshape(-1).contiguous()
+    assert obs.dtype == th.float32 and actions.dtype == th.int64 and obs.shape[0] == actions.shape[0]
+    rows = obs.shape[0]
+    out = th.empty(rows, O + n_agents + n_actions, dtype=th.float32, device=obs.device)
+    with th.cuda.device(obs.device):
+        _abi.check(_abi.lib().ec_disc_rows(C.c_void_p(obs.data_ptr()), C.c_void_p(actions.data_ptr()), rows, O, n_agents, n_actions,
+                                           C.c_void_p(out.data_ptr()), C.c_void_p(th.cuda.current_stream(obs.device).cuda_stream)),
+                   "ec_disc_rows")
+    return out

@@ -258,3 +258,24 @@ def test_discriminator_no_grad_pass_fused_tails(rows, n_agents, n_actions, monke
     monkeypatch.setattr(gn, "_explicit_mask", lambda x_, p_: None)
     with th.no_grad():
         assert not a._fused_tails_ok(x)
+
+
+@pytest.mark.parametrize("B,T,N,A", [(3, 5, 10, 11), (7, 100, 40, 41), (1, 1, 2, 3), (300, 9, 10, 11)])
+def test_disc_rows_equals_cat_of_one_hots(B, T, N, A):
+    """ec_disc_rows against the torch construction of the discriminator's input (gail_agent.py:131-141: obs with the agent
+    one-hot appended, concatenated with the one-hot action): exact."""
+    import ctypes as C
+    from marl_amd import _abi
+    from marl_amd.utils import linear_device
+    gen = th.Generator().manual_seed(B * T + N)
+    obs = th.randn(B, T, N, 9, generator=gen).cuda()
+    actions = th.randint(0, A, (B, T, N, 1), generator=gen).cuda()
+    got = linear_device.disc_rows(obs, actions, N, A)
+    eye = th.eye(N, device="cuda").expand(B, T, N, N)
+    want = th.cat([obs, eye, th.nn.functional.one_hot(actions.squeeze(-1), num_classes=A).float()], dim=-1).reshape(-1, 9 + N + A)
+    assert got.shape == want.shape and th.equal(got, want)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
+    assert _abi.lib().ec_disc_rows(vp(obs), vp(actions), B * T * N, 9, 0, A, vp(got), stream) != 0
+    assert _abi.lib().ec_disc_rows(vp(obs), C.c_void_p(0), B * T * N, 9, N, A, vp(got), stream) != 0
+    assert _abi.lib().ec_disc_rows(vp(obs), vp(actions), 0, 9, N, A, vp(got), stream) == 0
