@@ -172,7 +172,8 @@ def test_linear_fwd_matches_float64(rows, k_in, c_out):
 
 
 @pytest.mark.parametrize("rows,k_in,c_out,p", [(70001, 128, 64, 0.3), (4097, 64, 32, 0.3), (100003, 32, 1, 0.2),
-                                               (33, 128, 128, 0.0), (2, 36, 40, 0.5)])
+                                               (33, 128, 128, 0.0), (2, 36, 40, 0.5), (517, 30, 16, 0.25),
+                                               (4099, 97, 5, 0.1)])
 def test_linear_fwd_bn_equals_tail_then_linear(rows, k_in, c_out, p):
     """ec_linear_fwd_bn (the BatchNorm -> ReLU -> Dropout tail applied inside the next Linear's kernel) against the two
     kernels it replaces, ec_bn_relu_dropout_fwd then ec_linear_fwd, for the same seed: bit for bit (same arithmetic, same
