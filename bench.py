@@ -362,7 +362,7 @@ def main():
         one["traffic"], one["traffic_source"] = recorded_traffic() if std else (None, None)
         one["note"] = ("one launch per env step from a Python loop: the host issues slower than the kernel runs, so an event "
                        "pair around a launch also spans its launch latency; the median is the figure free of it (rocprofv3 "
-                       "kernel time of the same launches: profiles/r02/bench_kernel_stats.csv, k_step<4, 4, false>)")
+                       "kernel time of the same launches: profiles/r02/bench_kernel_stats.csv, k_step<.., false>)")
         many = {"bound": "hbm", "achieved": bytes_step * T / (ravg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "kernel": "k_step<.., looping>", "env_steps_per_launch": T,
                 "kernel_avg_us": ravg_ms * 1e3, "kernel_median_us": rmed_ms * 1e3,
