@@ -453,15 +453,19 @@ int ec_linear_fwd(const float* x, const float* w, const float* b, int64_t rows, 
 /* The same with the previous layer's BatchNorm -> ReLU -> Dropout tail applied on the way in:
  * y = (relu(x * scale + shift) * keep / (1 - p)) W^T + b, keep = ec_bn_relu_dropout_fwd's counter-based draw for `seed`
  * (element index row * k_in + col), 0 <= p < 1.  The activated [rows, k_in] tensor is never written: for passes that
- * keep nothing for a backward (gail_agent.py:165-167, the reward pass under no_grad with the network in training mode). */
+ * keep nothing for a backward (gail_agent.py:165-167, the reward pass under no_grad with the network in training mode).
+ * partials: NULL, or [n_partials <= 1024][2][c_out] <- per-block column sums of (y - b) and (y - b)^2: the input of
+ * ec_bn_finalize for the next layer's BatchNorm with x_row0 = b (its statistics pass, without reading y again); needs b. */
+int ec_linear_fwd_bn(const float* x, const float* scale, const float* shift, uint64_t seed, float p, const float* w,
+                     const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y, int32_t n_partials, float* partials,
+                     void* stream);
+
 /* The GAIL discriminator's input rows (gail_agent.py:131-141, gail_network.py:127-131: obs with the agent's one-hot id,
  * concatenated with the one-hot action): out [rows, obs_dim + n_agents + n_actions] fp32 from obs [rows, obs_dim] fp32 and
  * actions [rows] int64, rows in [.., agent] order (row r belongs to agent r % n_agents).  One write of the rows instead of
  * two torch.cat passes and a one_hot. */
 int ec_disc_rows(const float* obs, const int64_t* actions, int64_t rows, int32_t obs_dim, int32_t n_agents, int32_t n_actions,
                  float* out, void* stream);
-int ec_linear_fwd_bn(const float* x, const float* scale, const float* shift, uint64_t seed, float p, const float* w,
-                     const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y, void* stream);
 
 /* Weight and bias gradient of a Linear layer over a tall batch (gail_network.py:97-125, the discriminator's layers on
  * 4.1 M .. 65.5 M rows): dW [c_out, k_in] = dy^T x, db [c_out] = sum_rows dy for dy [rows, c_out], x [rows, k_in] fp32,

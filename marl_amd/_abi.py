@@ -174,7 +174,7 @@ def lib():
     L.ec_linear_wgrad.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     L.ec_linear_fwd.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp]
     L.ec_disc_rows.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
-    L.ec_linear_fwd_bn.argtypes = [vp, vp, vp, u64, f32, vp, vp, i64, i32, i32, vp, vp]
+    L.ec_linear_fwd_bn.argtypes = [vp, vp, vp, u64, f32, vp, vp, i64, i32, i32, vp, i32, vp, vp]
     L.ec_bn_finalize.argtypes = [vp, i32, vp, i64, i32, vp, vp, f32, f32] + [vp] * 9
     L.ec_bn_bwd_coeffs.argtypes = [vp, i32, vp, vp, vp, i64, i32] + [vp] * 6
     L.ec_bn_relu_dropout_fwd.argtypes = [vp, vp, vp, vp, u64, f32, i64, i32, vp, vp]

@@ -25,6 +25,10 @@ struct LinArgs {
     uint64_t seed;
     uint32_t thr24;
     float inv_keep;
+    // BN, optional: the batch statistics of y for the NEXT BatchNorm, as ec_bn_col_stats leaves them for ec_bn_finalize:
+    // partials [gridDim.x][2][C] <- this block's sums over its rows of (y - b) and (y - b)^2 (the pivot is the bias row)
+    float* partials;
+    int n_partials;
 };
 
 // (the keep flags are ec_bn.hip's keep_draw(seed, row * K + col), restated in the kernel with the per-row work hoisted: the
@@ -49,6 +53,10 @@ __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
     const int j = lane & 31, half = lane >> 5;
     const bool vec = (K & 3) == 0;  // rows are 16-byte aligned
     const int64_t n_tiles = (p.rows + 31) / 32;
+    const bool stats = BN && p.partials != nullptr;
+    float st1[TO], st2[TO];   // lane (out j, half): sums over the rows it held of output 32 to + j
+#pragma unroll
+    for (int to = 0; to < TO; to++) st1[to] = st2[to] = 0.0f;
     for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += (int64_t)gridDim.x * nw) {
         const int64_t rowbase = tile * 32, row = rowbase + j;  // as the A operand, lane (j, half) is row j
         const bool ok = row < p.rows;
@@ -142,6 +150,20 @@ __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
                 for (int q = 0; q < 4; q++) xa[q] = xn[q];
             }
         }
+        if (stats) {
+#pragma unroll
+            for (int to = 0; to < TO; to++) {
+                const float pivot = s_b[32 * to + j];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float d = acc[to][r] - pivot;
+                    if (rowbase + 8 * (r >> 2) + 4 * half + (r & 3) < p.rows) {
+                        st1[to] += d;
+                        st2[to] += d * d;
+                    }
+                }
+            }
+        }
         // register r of lane (out j, half): row 8 (r >> 2) + 4 half + (r & 3) of the tile
 #pragma unroll
         for (int to = 0; to < TO; to++)
@@ -150,6 +172,22 @@ __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
                 const int64_t orow = rowbase + 8 * (r >> 2) + 4 * half + (r & 3);
                 if (orow < p.rows && 32 * to + j < C) p.y[orow * C + 32 * to + j] = acc[to][r];
             }
+    }
+    if (stats) {   // the block's eight (wave, half) sums per output, added in a fixed order; the fragments are done with
+        __syncthreads();
+        float* s_red = lds;   // [2][8][32 TO]
+#pragma unroll
+        for (int to = 0; to < TO; to++) {
+            s_red[(0 * 8 + wave * 2 + half) * 32 * TO + 32 * to + j] = st1[to];
+            s_red[(1 * 8 + wave * 2 + half) * 32 * TO + 32 * to + j] = st2[to];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            const int which = i / C, c = i - which * C;
+            float sum = 0.0f;
+            for (int k = 0; k < 2 * nw; k++) sum += s_red[(which * 8 + k) * 32 * TO + c];
+            p.partials[((size_t)blockIdx.x * 2 + which) * C + c] = sum;
+        }
     }
 }
 
@@ -180,6 +218,7 @@ int launch_linear(const LinArgs& a, hipStream_t stream) {
     const int64_t tiles = (a.rows + 31) / 32;
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > 1024) blocks = 1024;
+    if (a.partials) blocks = a.n_partials;   // one partial per block: the caller sized the buffer (blocks without rows write zeros)
     hipLaunchKernelGGL((k_linear_fwd<TO, TI, BN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
     EC_HIP(hipGetLastError());
     return EC_OK;
@@ -214,21 +253,28 @@ extern "C" int ec_linear_fwd(const float* x, const float* w, const float* b, int
     if (!x || !w || !y) return ec::fail(EC_EINVAL, "ec_linear_fwd: null pointer");
     if (rows < 0 || k_in < 1 || k_in > 128 || c_out < 1 || c_out > 128)
         return ec::fail(EC_EINVAL, "ec_linear_fwd: rows %lld, k_in %d, c_out %d (1..128 each)", (long long)rows, k_in, c_out);
-    const LinArgs a{x, w, b, rows, k_in, c_out, y, nullptr, nullptr, 0, 0, 1.0f};
+    const LinArgs a{x, w, b, rows, k_in, c_out, y, nullptr, nullptr, 0, 0, 1.0f, nullptr, 0};
     return launch_linear_to<false>(a, (hipStream_t)stream);
 }
 
 // y = dropout(relu(x * scale + shift), p) W^T + b: the BatchNorm -> ReLU -> Dropout tail of the previous layer (scale, shift
 // from ec_bn_finalize; the keep flags are ec_bn_relu_dropout_fwd's draws for the same seed) applied on the way in, so the
 // activated [rows, k_in] tensor is never written.  For passes that keep nothing for a backward (GAIL's reward pass).
+// partials (optional, [n_partials][2][c_out], 1 <= n_partials <= 1024 blocks): the column sums of (y - b) and (y - b)^2 per
+// block, what ec_bn_col_stats would leave for ec_bn_finalize with the bias row as the pivot -- the statistics pass of the
+// next BatchNorm without reading y again.  Needs b.
 extern "C" int ec_linear_fwd_bn(const float* x, const float* scale, const float* shift, uint64_t seed, float p, const float* w,
-                                const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y, void* stream) {
+                                const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y, int32_t n_partials,
+                                float* partials, void* stream) {
     if (rows == 0) return EC_OK;
     if (!x || !scale || !shift || !w || !y) return ec::fail(EC_EINVAL, "ec_linear_fwd_bn: null pointer");
     if (rows < 0 || k_in < 1 || k_in > 128 || c_out < 1 || c_out > 128)
         return ec::fail(EC_EINVAL, "ec_linear_fwd_bn: rows %lld, k_in %d, c_out %d (1..128 each)", (long long)rows, k_in, c_out);
     if (!(p >= 0.0f && p < 1.0f)) return ec::fail(EC_EINVAL, "ec_linear_fwd_bn: dropout p %g outside [0, 1)", (double)p);
-    const LinArgs a{x, w, b, rows, k_in, c_out, y, scale, shift, seed, (uint32_t)((double)p * 16777216.0), 1.0f / (1.0f - p)};
+    if (partials && (!b || n_partials < 1 || n_partials > 1024))
+        return ec::fail(EC_EINVAL, "ec_linear_fwd_bn: statistics need the bias and 1..1024 partials (got %d)", n_partials);
+    const LinArgs a{x, w, b, rows, k_in, c_out, y, scale, shift, seed, (uint32_t)((double)p * 16777216.0), 1.0f / (1.0f - p),
+                    partials, partials ? n_partials : 0};
     return launch_linear_to<true>(a, (hipStream_t)stream);
 }
 

@@ -148,29 +148,37 @@ def _draw_seed():
     return int(th.empty((), dtype=th.int64).random_())
 
 
-def _bn_batch_stats(x, weight, bias, eps, running):
+def _bn_batch_stats(x, weight, bias, eps, running, partials=None, pivot=None):
     """mean, var, invstd, scale, shift [C] of a training-mode BatchNorm over x [rows, C] (fp32, on the device), and the
     module's running statistics updated: one streaming pass (ec_bn_col_stats; torch.var_mean's column reduction runs at
     a third of the HBM rate) leaving per-block partial sums about the pivot row x[0], then ec_bn_finalize, which adds
     them up in float64 and derives everything per-column in one launch.
     running: (running_mean, running_var, num_batches_tracked, momentum or None) or None; updated through raw pointers
-    (autograd does not see the buffers change)."""
+    (autograd does not see the buffers change).
+    partials [n, 2, C] with pivot [C]: the statistics pass was already done by the kernel that wrote x (ec_linear_fwd_bn's
+    sums of (x - pivot) and (x - pivot)^2); only ec_bn_finalize runs."""
     import ctypes as C
 
     from marl_amd import _abi
     rows, Cc = x.shape
     stream = C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-    n_part = int(min(_BnReluDropHipFn.N_PARTIALS, max(1, rows // 64)))
-    partials = th.empty(n_part, 2, Cc, dtype=th.float32, device=x.device)
+    have = partials is not None
+    if have:
+        n_part = partials.shape[0]
+    else:
+        n_part = int(min(_BnReluDropHipFn.N_PARTIALS, max(1, rows // 64)))
+        partials = th.empty(n_part, 2, Cc, dtype=th.float32, device=x.device)
+        pivot = x   # (its first row)
     cols = th.empty(5, Cc, dtype=th.float32, device=x.device)
     mean, var, invstd, scale, shift = cols.unbind(0)
     rm, rv, nbt, momentum = running if running is not None else (None, None, None, 0.0)
     if nbt is not None:
         nbt.data += 1  # (before the launch: momentum=None weighs this batch 1 / count)
     with th.cuda.device(x.device):
-        _abi.check(_abi.lib().ec_bn_col_stats(ptr(x), rows, Cc, n_part, ptr(partials), stream), "ec_bn_col_stats")
-        _abi.check(_abi.lib().ec_bn_finalize(ptr(partials), n_part, ptr(x), rows, Cc, ptr(weight), ptr(bias), C.c_float(eps),
+        if not have:
+            _abi.check(_abi.lib().ec_bn_col_stats(ptr(x), rows, Cc, n_part, ptr(partials), stream), "ec_bn_col_stats")
+        _abi.check(_abi.lib().ec_bn_finalize(ptr(partials), n_part, ptr(pivot), rows, Cc, ptr(weight), ptr(bias), C.c_float(eps),
                                              C.c_float(-1.0 if momentum is None else float(momentum)), ptr(rm), ptr(rv),
                                              ptr(nbt), ptr(mean), ptr(var), ptr(invstd), ptr(scale), ptr(shift), stream),
                    "ec_bn_finalize")
@@ -337,14 +345,20 @@ class Discriminator(nn.Module):
         statistics pass over the Linear's output, then BatchNorm -> ReLU -> Dropout applied inside the NEXT Linear's
         kernel, with the draws (one seed per layer, in layer order) the two-step path would make"""
         x = self.fc1(x)
+        partials = pivot = None
         for i in (1, 2, 3):
             bn, drop, nxt = getattr(self, "bn%d" % i), getattr(self, "dropout%d" % i), getattr(self, "fc%d" % (i + 1))
             running = None
             if bn.track_running_stats:
                 running = (bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum)
             x = x.contiguous()
-            _, _, _, scale, shift = _bn_batch_stats(x, bn.weight, bn.bias, bn.eps, running)
-            x = linear_device.fwd_bn(x, scale, shift, _draw_seed(), float(drop.p), nxt.weight, nxt.bias)
+            _, _, _, scale, shift = _bn_batch_stats(x, bn.weight, bn.bias, bn.eps, running, partials, pivot)
+            # (the kernel that writes layer i + 1's pre-activations also leaves their column sums for bn(i + 1), about
+            # the layer's bias as the pivot: its inputs are normalised activations, so the outputs stay within a few
+            # standard deviations of the bias and the one-pass variance does not cancel)
+            want = i < 3 and nxt.bias is not None
+            out = linear_device.fwd_bn(x, scale, shift, _draw_seed(), float(drop.p), nxt.weight, nxt.bias, want_stats=want)
+            x, partials, pivot = (out[0], out[1], nxt.bias.detach()) if want else (out, None, None)
         return x
 
     def forward_rows(self, x):

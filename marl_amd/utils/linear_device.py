@@ -56,20 +56,28 @@ def fwd_bn_ok(x, w):
             and x.shape[1] == w.shape[1] and 1 <= x.shape[1] <= 128 and 1 <= w.shape[0] <= 128 and not th.is_grad_enabled())
 
 
-def fwd_bn(x, scale, shift, seed, p, w, b=None):
+def fwd_bn(x, scale, shift, seed, p, w, b=None, want_stats=False):
     """dropout(relu(x * scale + shift), p) @ w.t() + b with the keep flags of ec_bn_relu_dropout_fwd for `seed`
-    (ec_linear_fwd_bn): nothing of the activated tensor is written"""
+    (ec_linear_fwd_bn): nothing of the activated tensor is written.
+    want_stats (needs b): returns (y, partials [n, 2, c_out]) -- per-block column sums of (y - b) and (y - b)^2, the
+    input of ec_bn_finalize for a BatchNorm over y with b as the pivot row"""
     x, w = x.contiguous(), w.contiguous()
     rows, k_in = x.shape
     c_out = w.shape[0]
     y = th.empty(rows, c_out, dtype=th.float32, device=x.device)
+    b = b.contiguous() if b is not None else None
+    partials, n_part = None, 0
+    if want_stats:
+        assert b is not None
+        n_part = int(min(1024, max(1, (rows + 127) // 128)))
+        partials = th.empty(n_part, 2, c_out, dtype=th.float32, device=x.device)
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
     with th.cuda.device(x.device):
         _abi.check(_abi.lib().ec_linear_fwd_bn(ptr(x), ptr(scale.contiguous()), ptr(shift.contiguous()), C.c_uint64(seed),
-                                               C.c_float(p), ptr(w), ptr(b.contiguous() if b is not None else None), rows, k_in,
-                                               c_out, ptr(y), C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)),
+                                               C.c_float(p), ptr(w), ptr(b), rows, k_in, c_out, ptr(y), n_part, ptr(partials),
+                                               C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)),
                    "ec_linear_fwd_bn")
-    return y
+    return (y, partials) if want_stats else y
 
 
 def disc_rows(obs, actions, n_agents, n_actions):

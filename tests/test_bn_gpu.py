@@ -206,6 +206,15 @@ def test_linear_fwd_bn_equals_tail_then_linear(rows, k_in, c_out, p):
                 assert th.equal(got, two_step)
                 want = act.double() @ w.double().t() + (bias.double() if bias is not None else 0.0)
                 assert float((got.double() - want).abs().max()) <= 2e-6 * float(want.abs().max() + 1)
+        # the optional statistics epilogue: y unchanged, partials add up to the column sums of (y - b) and (y - b)^2
+        y_plain = linear_device.fwd_bn(x, scale, shift, seed, p, w, b)
+        y_stats, partials = linear_device.fwd_bn(x, scale, shift, seed, p, w, b, want_stats=True)
+        assert th.equal(y_plain, y_stats) and partials.shape[1:] == (2, c_out)
+        d = y_stats.double() - b.double()
+        got_s = partials.double().sum(0)
+        for which, want_s in ((0, d.sum(0)), (1, (d * d).sum(0))):
+            scale_ = (d.abs() if which == 0 else d * d).sum(0) + 1e-30
+            assert float(((got_s[which] - want_s).abs() / scale_).max()) < 2e-6, which
         if act is None:   # identity weight block reads the activated values back out of the fused kernel
             eye = th.eye(k_in, device="cuda")
             a_out = th.cat([linear_device.fwd_bn(x, scale, shift, seed, p, eye[i:i + 32].contiguous()) for i in range(0, k_in, 32)], 1)
@@ -215,9 +224,9 @@ def test_linear_fwd_bn_equals_tail_then_linear(rows, k_in, c_out, p):
             assert abs(float((a_out != 0).float().mean()) - float((y > 0).float().mean()) * (1 - p)) < 0.25
     # argument checks
     lib = _abi.lib()
-    assert lib.ec_linear_fwd_bn(vp(x), vp(scale), vp(shift), C.c_uint64(1), C.c_float(1.0), vp(w), vp(b), rows, k_in, c_out, vp(x), stream) != 0
-    assert lib.ec_linear_fwd_bn(vp(x), vp(scale), vp(shift), C.c_uint64(1), C.c_float(0.1), vp(w), vp(b), rows, 129, c_out, vp(x), stream) != 0
-    assert lib.ec_linear_fwd_bn(vp(x), C.c_void_p(0), vp(shift), C.c_uint64(1), C.c_float(0.1), vp(w), vp(b), rows, k_in, c_out, vp(x), stream) != 0
+    assert lib.ec_linear_fwd_bn(vp(x), vp(scale), vp(shift), C.c_uint64(1), C.c_float(1.0), vp(w), vp(b), rows, k_in, c_out, vp(x), 0, C.c_void_p(0), stream) != 0
+    assert lib.ec_linear_fwd_bn(vp(x), vp(scale), vp(shift), C.c_uint64(1), C.c_float(0.1), vp(w), vp(b), rows, 129, c_out, vp(x), 0, C.c_void_p(0), stream) != 0
+    assert lib.ec_linear_fwd_bn(vp(x), C.c_void_p(0), vp(shift), C.c_uint64(1), C.c_float(0.1), vp(w), vp(b), rows, k_in, c_out, vp(x), 0, C.c_void_p(0), stream) != 0
 
 
 @pytest.mark.parametrize("rows,n_agents,n_actions", [(50000, 10, 11), (20000, 40, 41)])

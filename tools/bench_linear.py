@@ -49,10 +49,14 @@ for k_in, c_out, p in ((128, 64, 0.3), (64, 32, 0.3), (32, 1, 0.2)):
     w, b = th.randn(c_out, k_in, device="cuda") * 0.2, th.randn(c_out, device="cuda")
     y, act = th.empty(rows, c_out, device="cuda"), th.empty(rows, k_in, device="cuda")
     t0 = timed(lambda: _abi.check(L.ec_linear_fwd_bn(vp(x), vp(sc), vp(sh), C.c_uint64(7), C.c_float(p), vp(w), vp(b), rows, k_in,
-                                                     c_out, vp(y), stream), "ec_linear_fwd_bn"))
+                                                     c_out, vp(y), 0, vp(None), stream), "ec_linear_fwd_bn"))
+    part = th.empty(1024, 2, c_out, device="cuda")
+    t0s = timed(lambda: _abi.check(L.ec_linear_fwd_bn(vp(x), vp(sc), vp(sh), C.c_uint64(7), C.c_float(p), vp(w), vp(b), rows, k_in,
+                                                      c_out, vp(y), 1024, vp(part), stream), "ec_linear_fwd_bn"))
     t1 = timed(lambda: _abi.check(L.ec_bn_relu_dropout_fwd(vp(x), vp(sc), vp(sh), vp(None), C.c_uint64(7), C.c_float(p), rows, k_in,
                                                            vp(act), stream), "ec_bn_relu_dropout_fwd"))
     t2 = timed(lambda: _abi.check(L.ec_linear_fwd(vp(act), vp(w), vp(b), rows, k_in, c_out, vp(y), stream), "ec_linear_fwd"))
     t3 = timed(lambda: F.linear(act, w, b))
+    print("rows %d  %3d -> %3d  with the column sums of y: %7.1f us" % (rows, k_in, c_out, t0s * 1e6))
     print("rows %d  %3d -> %3d  ec_linear_fwd_bn %7.1f us (%.2f TB/s)   tail %7.1f us + layer %7.1f us (F.linear %7.1f us)" % (
         rows, k_in, c_out, t0 * 1e6, rows * (k_in + c_out) * 4 / t0 / 1e12, t1 * 1e6, t2 * 1e6, t3 * 1e6))
