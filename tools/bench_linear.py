@@ -31,7 +31,7 @@ def timed(fn, reps=10):
 
 
 th.set_grad_enabled(False)
-for k_in, c_out in ((30, 128), (128, 64), (64, 32), (32, 64), (64, 128), (128, 30)):
+for k_in, c_out in ((30, 128), (128, 64), (64, 32), (32, 64), (64, 128), (128, 30), (90, 128), (96, 128)):
     x = th.randn(rows, k_in, device="cuda")
     w, b = th.randn(c_out, k_in, device="cuda") * 0.2, th.randn(c_out, device="cuda")
     y = th.empty(rows, c_out, device="cuda")
