@@ -450,6 +450,11 @@ int ec_adam_clip_step(int32_t n_nets, const int32_t* n_tensors, float* const* pa
  * (rows as the MFMA's M dimension).  Replaces F.linear for these shapes. */
 int ec_linear_fwd(const float* x, const float* w, const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y,
                   void* stream);
+/* ec_linear_fwd that also leaves the batch statistics of y for a BatchNorm that follows (gail_network.py:97-125: fc -> bn):
+ * partials [n_partials <= 1024][2][c_out] <- per-block column sums of (y - pivot) and (y - pivot)^2, the input of
+ * ec_bn_finalize with x_row0 = pivot; pivot [c_out] = a row of y (the caller's one-row call).  Saves the statistics pass. */
+int ec_linear_fwd_stats(const float* x, const float* w, const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y,
+                        const float* pivot, int32_t n_partials, float* partials, void* stream);
 /* The same with the previous layer's BatchNorm -> ReLU -> Dropout tail applied on the way in:
  * y = (relu(x * scale + shift) * keep / (1 - p)) W^T + b, keep = ec_bn_relu_dropout_fwd's counter-based draw for `seed`
  * (element index row * k_in + col), 0 <= p < 1.  The activated [rows, k_in] tensor is never written: for passes that

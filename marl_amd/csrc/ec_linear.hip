@@ -25,24 +25,30 @@ struct LinArgs {
     uint64_t seed;
     uint32_t thr24;
     float inv_keep;
-    // BN, optional: the batch statistics of y for the NEXT BatchNorm, as ec_bn_col_stats leaves them for ec_bn_finalize:
-    // partials [gridDim.x][2][C] <- this block's sums over its rows of (y - b) and (y - b)^2 (the pivot is the bias row)
+    // optional: the batch statistics of y for the NEXT BatchNorm, as ec_bn_col_stats leaves them for ec_bn_finalize:
+    // partials [gridDim.x][2][C] <- this block's sums over its rows of (y - pivot) and (y - pivot)^2; pivot [C], or NULL:
+    // the bias row
     float* partials;
     int n_partials;
+    const float* pivot;
 };
 
 // (the keep flags are ec_bn.hip's keep_draw(seed, row * K + col), restated in the kernel with the per-row work hoisted: the
 // two must stay the same function -- tests compare the fused layer with the two-step one bit for bit)
-template <int TO, int TI, bool BN>
+template <int TO, int TI, bool BN, bool ST>   // ST: the plain layer with the statistics epilogue (BN takes it at run time)
 __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
     extern __shared__ __align__(16) float lds[];
     float* s_f = lds;                      // fragments: 16 TI steps x TO tiles x 64 lanes
     float* s_b = s_f + 16 * TI * TO * 64;  // [32 TO] bias
     float* s_sc = s_b + 32 * TO;           // BN: [32 TI] scale, [32 TI] shift
     float* s_sh = s_sc + 32 * TI;
+    float* s_pv = s_sh + 32 * TI;          // [32 TO] pivot of the statistics
     const int K = p.K, C = p.C;
     stage_frag(s_f, p.w, K, 1, C, K, 16 * TI, TO, true);
-    for (int i = threadIdx.x; i < 32 * TO; i += blockDim.x) s_b[i] = (p.b && i < C) ? p.b[i] : 0.0f;
+    for (int i = threadIdx.x; i < 32 * TO; i += blockDim.x) {
+        s_b[i] = (p.b && i < C) ? p.b[i] : 0.0f;
+        s_pv[i] = i < C ? (p.pivot ? p.pivot[i] : s_b[i]) : 0.0f;
+    }
     if (BN)
         for (int i = threadIdx.x; i < 32 * TI; i += blockDim.x) {
             s_sc[i] = i < K ? p.scale[i] : 0.0f;
@@ -53,7 +59,7 @@ __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
     const int j = lane & 31, half = lane >> 5;
     const bool vec = (K & 3) == 0;  // rows are 16-byte aligned
     const int64_t n_tiles = (p.rows + 31) / 32;
-    const bool stats = BN && p.partials != nullptr;
+    const bool stats = (BN || ST) && p.partials != nullptr;   // (in the plain kernels the accumulators cost up to a third)
     float st1[TO], st2[TO];   // lane (out j, half): sums over the rows it held of output 32 to + j
 #pragma unroll
     for (int to = 0; to < TO; to++) st1[to] = st2[to] = 0.0f;
@@ -153,7 +159,7 @@ __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
         if (stats) {
 #pragma unroll
             for (int to = 0; to < TO; to++) {
-                const float pivot = s_b[32 * to + j];
+                const float pivot = s_pv[32 * to + j];
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const float d = acc[to][r] - pivot;
@@ -210,38 +216,38 @@ __global__ void __launch_bounds__(256) k_disc_rows(const float* __restrict__ obs
     }
 }
 
-template <int TO, int TI, bool BN>
+template <int TO, int TI, bool BN, bool ST>
 int launch_linear(const LinArgs& a, hipStream_t stream) {
-    const size_t lds = sizeof(float) * ((size_t)16 * TI * TO * 64 + 32 * TO + 64 * TI);
-    EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_fwd<TO, TI, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const size_t lds = sizeof(float) * ((size_t)16 * TI * TO * 64 + 64 * TO + 64 * TI);
+    EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_fwd<TO, TI, BN, ST>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
     const int64_t tiles = (a.rows + 31) / 32;
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > 1024) blocks = 1024;
     if (a.partials) blocks = a.n_partials;   // one partial per block: the caller sized the buffer (blocks without rows write zeros)
-    hipLaunchKernelGGL((k_linear_fwd<TO, TI, BN>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((k_linear_fwd<TO, TI, BN, ST>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
     EC_HIP(hipGetLastError());
     return EC_OK;
 }
 
-template <int TO, bool BN>
+template <int TO, bool BN, bool ST>
 int launch_linear_ti(const LinArgs& a, int TI, hipStream_t stream) {
     switch (TI) {
-        case 1: return launch_linear<TO, 1, BN>(a, stream);
-        case 2: return launch_linear<TO, 2, BN>(a, stream);
-        case 3: return launch_linear<TO, 3, BN>(a, stream);
-        default: return launch_linear<TO, 4, BN>(a, stream);
+        case 1: return launch_linear<TO, 1, BN, ST>(a, stream);
+        case 2: return launch_linear<TO, 2, BN, ST>(a, stream);
+        case 3: return launch_linear<TO, 3, BN, ST>(a, stream);
+        default: return launch_linear<TO, 4, BN, ST>(a, stream);
     }
 }
 
-template <bool BN>
+template <bool BN, bool ST = false>
 int launch_linear_to(const LinArgs& a, hipStream_t stream) {
     const int TI = (a.K + 31) / 32;
     switch ((a.C + 31) / 32) {
-        case 1: return launch_linear_ti<1, BN>(a, TI, stream);
-        case 2: return launch_linear_ti<2, BN>(a, TI, stream);
-        case 3: return launch_linear_ti<3, BN>(a, TI, stream);
-        default: return launch_linear_ti<4, BN>(a, TI, stream);
+        case 1: return launch_linear_ti<1, BN, ST>(a, TI, stream);
+        case 2: return launch_linear_ti<2, BN, ST>(a, TI, stream);
+        case 3: return launch_linear_ti<3, BN, ST>(a, TI, stream);
+        default: return launch_linear_ti<4, BN, ST>(a, TI, stream);
     }
 }
 
@@ -253,8 +259,21 @@ extern "C" int ec_linear_fwd(const float* x, const float* w, const float* b, int
     if (!x || !w || !y) return ec::fail(EC_EINVAL, "ec_linear_fwd: null pointer");
     if (rows < 0 || k_in < 1 || k_in > 128 || c_out < 1 || c_out > 128)
         return ec::fail(EC_EINVAL, "ec_linear_fwd: rows %lld, k_in %d, c_out %d (1..128 each)", (long long)rows, k_in, c_out);
-    const LinArgs a{x, w, b, rows, k_in, c_out, y, nullptr, nullptr, 0, 0, 1.0f, nullptr, 0};
+    const LinArgs a{x, w, b, rows, k_in, c_out, y, nullptr, nullptr, 0, 0, 1.0f, nullptr, 0, nullptr};
     return launch_linear_to<false>(a, (hipStream_t)stream);
+}
+
+// ec_linear_fwd that also leaves the column sums of its output for a BatchNorm over y: partials [n_partials][2][c_out] <-
+// per-block sums of (y - pivot) and (y - pivot)^2, the input of ec_bn_finalize with x_row0 = pivot.  pivot [c_out]: any
+// row of y's scale (the caller computes y's first row with a one-row call).
+extern "C" int ec_linear_fwd_stats(const float* x, const float* w, const float* b, int64_t rows, int32_t k_in, int32_t c_out,
+                                   float* y, const float* pivot, int32_t n_partials, float* partials, void* stream) {
+    if (!x || !w || !y || !pivot || !partials) return ec::fail(EC_EINVAL, "ec_linear_fwd_stats: null pointer");
+    if (rows < 1 || k_in < 1 || k_in > 128 || c_out < 1 || c_out > 128 || n_partials < 1 || n_partials > 1024)
+        return ec::fail(EC_EINVAL, "ec_linear_fwd_stats: rows %lld, k_in %d, c_out %d (1..128 each), %d partials (1..1024)",
+                        (long long)rows, k_in, c_out, n_partials);
+    const LinArgs a{x, w, b, rows, k_in, c_out, y, nullptr, nullptr, 0, 0, 1.0f, partials, n_partials, pivot};
+    return launch_linear_to<false, true>(a, (hipStream_t)stream);
 }
 
 // y = dropout(relu(x * scale + shift), p) W^T + b: the BatchNorm -> ReLU -> Dropout tail of the previous layer (scale, shift
@@ -274,7 +293,7 @@ extern "C" int ec_linear_fwd_bn(const float* x, const float* scale, const float*
     if (partials && (!b || n_partials < 1 || n_partials > 1024))
         return ec::fail(EC_EINVAL, "ec_linear_fwd_bn: statistics need the bias and 1..1024 partials (got %d)", n_partials);
     const LinArgs a{x, w, b, rows, k_in, c_out, y, scale, shift, seed, (uint32_t)((double)p * 16777216.0), 1.0f / (1.0f - p),
-                    partials, partials ? n_partials : 0};
+                    partials, partials ? n_partials : 0, nullptr};
     return launch_linear_to<true>(a, (hipStream_t)stream);
 }
 

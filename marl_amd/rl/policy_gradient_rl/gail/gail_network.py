@@ -344,8 +344,11 @@ class Discriminator(nn.Module):
         """forward_rows for a no-grad pass in training mode (gail_agent.py:165-167, the reward pass): per layer the
         statistics pass over the Linear's output, then BatchNorm -> ReLU -> Dropout applied inside the NEXT Linear's
         kernel, with the draws (one seed per layer, in layer order) the two-step path would make"""
-        x = self.fc1(x)
         partials = pivot = None
+        if linear_device.fwd_ok(x, self.fc1.weight):   # the first layer's statistics from the kernel that computes it
+            x, partials, pivot = linear_device.fwd(x, self.fc1.weight, self.fc1.bias, want_stats=True)
+        else:
+            x = self.fc1(x)
         for i in (1, 2, 3):
             bn, drop, nxt = getattr(self, "bn%d" % i), getattr(self, "dropout%d" % i), getattr(self, "fc%d" % (i + 1))
             running = None

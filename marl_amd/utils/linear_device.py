@@ -37,13 +37,25 @@ def fwd_ok(x, w):
             and x.shape[1] == w.shape[1] and 1 <= x.shape[1] <= 64 and 1 <= w.shape[0] <= 128 and not th.is_grad_enabled())
 
 
-def fwd(x, w, b=None):
-    """x @ w.t() + b for x [rows, k_in], w [c_out, k_in] (ec_linear_fwd)"""
+def fwd(x, w, b=None, want_stats=False):
+    """x @ w.t() + b for x [rows, k_in], w [c_out, k_in] (ec_linear_fwd).
+    want_stats: returns (y, partials [n, 2, c_out], pivot [c_out]) -- per-block column sums of (y - pivot) and
+    (y - pivot)^2 (ec_linear_fwd_stats), the input of ec_bn_finalize for a BatchNorm over y; the pivot is y's first row"""
     x, w = x.contiguous(), w.contiguous()
     rows, k_in = x.shape
     c_out = w.shape[0]
     y = th.empty(rows, c_out, dtype=th.float32, device=x.device)
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    if want_stats:
+        b_ = b.contiguous() if b is not None else None
+        pivot = fwd(x[:1], w, b_).reshape(c_out)
+        n_part = int(min(1024, max(1, (rows + 127) // 128)))
+        partials = th.empty(n_part, 2, c_out, dtype=th.float32, device=x.device)
+        with th.cuda.device(x.device):
+            _abi.check(_abi.lib().ec_linear_fwd_stats(ptr(x), ptr(w), ptr(b_), rows, k_in, c_out, ptr(y), ptr(pivot), n_part,
+                                                      ptr(partials), C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)),
+                       "ec_linear_fwd_stats")
+        return y, partials, pivot
     with th.cuda.device(x.device):
         _abi.check(_abi.lib().ec_linear_fwd(ptr(x), ptr(w), ptr(b.contiguous() if b is not None else None), rows, k_in, c_out,
                                             ptr(y), C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)), "ec_linear_fwd")

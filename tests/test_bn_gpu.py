@@ -157,6 +157,14 @@ def test_linear_fwd_matches_float64(rows, k_in, c_out):
             got = linear_device.fwd(x, w, bias)
             want = x.double() @ w.double().t() + (bias.double() if bias is not None else 0.0)
             assert float((got.double() - want).abs().max()) <= 2e-6 * float(want.abs().max() + 1)
+        # ec_linear_fwd_stats: the same y, and partials that add up to the column sums about y's first row
+        y_s, partials, pivot = linear_device.fwd(x, w, b, want_stats=True)
+        assert th.equal(y_s, linear_device.fwd(x, w, b)) and th.equal(pivot, y_s[0])
+        d = y_s.double() - pivot.double()
+        got_s = partials.double().sum(0)
+        for which, want_s in ((0, d.sum(0)), (1, (d * d).sum(0))):
+            scale_ = (d.abs() if which == 0 else d * d).sum(0) + 1e-30
+            assert float(((got_s[which] - want_s).abs() / scale_).max()) < 2e-6, which
     if rows >= SplitKLinear.MIN_ROWS and c_out in (32, 64, 96, 128):
         a, ref = SplitKLinear(k_in, c_out).cuda(), th.nn.Linear(k_in, c_out).cuda()
         ref.load_state_dict(a.state_dict())
