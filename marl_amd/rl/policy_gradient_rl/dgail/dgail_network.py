@@ -46,9 +46,15 @@ class _SplitKLinearFn(th.autograd.Function):
     CHUNK = 1024
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, stats_out=None):
+        """stats_out: a list; where the HIP forward runs, (partials, pivot) of y's column sums is appended to it
+        (ec_linear_fwd_stats: a BatchNorm that follows needs no statistics pass of its own)"""
         ctx.save_for_backward(x, w)
         if linear_device.fwd_ok(x, w):  # (inside a Function's forward grad mode is off)
+            if stats_out is not None and b is not None:
+                y, partials, pivot = linear_device.fwd(x, w, b, want_stats=True)
+                stats_out.append((partials, pivot))
+                return y
             return linear_device.fwd(x, w, b)
         return F.linear(x, w, b)
 
@@ -78,7 +84,7 @@ class _SplitKLinearFn(th.autograd.Function):
                 gb = gy[:full].reshape(-1, c, gy.shape[1]).sum(1).sum(0)
                 if full < rows:
                     gb = gb + gy[full:].sum(0)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 class SplitKLinear(nn.Linear):
@@ -86,10 +92,10 @@ class SplitKLinear(nn.Linear):
 
     MIN_ROWS = 8192
 
-    def forward(self, x):
+    def forward(self, x, stats_out=None):
         if x.dim() == 2 and x.shape[0] >= self.MIN_ROWS:
             if th.is_grad_enabled():
-                return _SplitKLinearFn.apply(x, self.weight, self.bias)
+                return _SplitKLinearFn.apply(x, self.weight, self.bias, stats_out)
             if linear_device.fwd_ok(x, self.weight):  # no-grad evaluations (GAIL's reward pass)
                 return linear_device.fwd(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)

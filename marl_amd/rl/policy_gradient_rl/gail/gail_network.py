@@ -198,7 +198,7 @@ class _BnReluDropHipFn(th.autograd.Function):
         return vp, (vp(x), vp(scale), vp(shift), vp(mask), C.c_uint64(seed), C.c_float(p))
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, p, running=None):
+    def forward(ctx, x, weight, bias, eps, p, running=None, stats=None):
         """running: (running_mean, running_var, num_batches_tracked, momentum or None) of the module, updated in the
         same launch that finalises the statistics (through raw pointers: autograd does not see the buffers change)"""
         import ctypes as C
@@ -207,7 +207,8 @@ class _BnReluDropHipFn(th.autograd.Function):
         x = x.contiguous()
         rows, Cc = x.shape
         stream = C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)
-        mean, var, invstd, scale, shift = _bn_batch_stats(x, weight, bias, eps, running)
+        # (stats: (partials, pivot) left by the kernel that wrote x, ec_linear_fwd_stats -- no statistics pass here then)
+        mean, var, invstd, scale, shift = _bn_batch_stats(x, weight, bias, eps, running, *(stats or ()))
         mask = _explicit_mask(x, p)
         if mask is not None:
             mask = mask.to(device=x.device, dtype=th.uint8).contiguous()
@@ -244,7 +245,7 @@ class _BnReluDropHipFn(th.autograd.Function):
             dx = th.empty_like(x)
             _abi.check(_abi.lib().ec_bn_relu_dropout_bwd_dx(vp(dout), *head, vp(a), vp(b), vp(c), rows, Cc, vp(dx), stream),
                        "ec_bn_relu_dropout_bwd_dx")
-        return dx, s2, s1, None, None, None
+        return dx, s2, s1, None, None, None, None
 
 
 class TallBatchNorm1d(nn.BatchNorm1d):
@@ -269,13 +270,14 @@ class TallBatchNorm1d(nn.BatchNorm1d):
         C = self.num_features
         return self.training and C % 4 == 0 and C <= 256 and 256 % (C // 4) == 0 and self.weight is not None
 
-    def relu_dropout(self, x, p):
-        """dropout(relu(self(x)), p) for a training-mode input, as one autograd node (HIP kernels on the device)"""
+    def relu_dropout(self, x, p, stats=None):
+        """dropout(relu(self(x)), p) for a training-mode input, as one autograd node (HIP kernels on the device);
+        stats: (partials, pivot) of x's column sums when the kernel that wrote x left them"""
         if self.hip_ok(x):
             running = None
             if self.track_running_stats:  # updated by the kernel that finalises the statistics
                 running = (self.running_mean, self.running_var, self.num_batches_tracked, self.momentum)
-            y, _, _ = _BnReluDropHipFn.apply(x, self.weight, self.bias, self.eps, float(p), running)
+            y, _, _ = _BnReluDropHipFn.apply(x, self.weight, self.bias, self.eps, float(p), running, stats)
             return y
         y, mean, var = _TallBnReluDropFn.apply(x, self.weight, self.bias, self.eps, float(p))
         self._track(x.shape[0], mean, var)
@@ -369,10 +371,12 @@ class Discriminator(nn.Module):
         if self._fused_tails_ok(x):
             return self._forward_rows_fused_tails(x)
         for i in (1, 2, 3):
-            x = getattr(self, "fc%d" % i)(x)
+            stats = []   # (the layer's kernel leaves the column sums of its output where it is the HIP one)
+            x = getattr(self, "fc%d" % i)(x, stats)
             bn, drop = getattr(self, "bn%d" % i), getattr(self, "dropout%d" % i)
             if (bn.hip_ok(x) or bn.tall(x)) and drop.training and 0.0 <= drop.p < 1.0 and self.activate_func is F.relu:
-                x = bn.relu_dropout(x, drop.p)      # one autograd node for the layer's tail (memory at 10^7..10^8 rows)
+                # one autograd node for the layer's tail (memory at 10^7..10^8 rows)
+                x = bn.relu_dropout(x, drop.p, stats[0] if stats else None)
                 continue
             if x.shape[0] > 1:
                 x = bn(x)
