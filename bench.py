@@ -2,20 +2,24 @@
 """bench.py — BASELINE.json's headline metric on MI355X.
 
 Workload (BASELINE.json configs[1]): the batched edge_computing environment, 4096 envs x 10 agents per
-GPU, task_size_max=6000, uniform-random policy over the availability mask.  One "step" = one pass of
-the rollout hot path over the whole batch: the env step (offload, 10 mini-slots of execute/receive, statistics,
-generate_task) with the next observation + availability mask and the random policy's draw for the next step;
-every episode_limit steps the envs are reset as ParallelRunner does.  Inputs and all state are resident in HBM;
-nothing crosses PCIe inside the timed region.
+GPU, task_size_max=6000, uniform-random policy over the availability mask.  One bench "step" = ONE WHOLE EPISODE of
+the rollout hot path over the whole batch (warm up on whole episodes, time whole episodes): reset,
+first observation + mask, first actions, then episode_limit (100) env steps -- offload, 10 mini-slots of
+execute/receive, statistics, generate_task, the next observation + availability mask and the random policy's draw
+for the next step -- as ParallelRunner.run does.  `value` stays in agent-steps/s (envs x agents x episode_limit per
+bench step); `ms_per_step` is per episode.  Inputs and all state are resident in HBM; nothing crosses PCIe inside
+the timed region.
 
 --launch rollout (default): ec_rollout_random_policy, one launch per episode (the looping instantiation of k_step).
 --launch graph / eager:     ec_step_random_policy, one launch per step (replayed from a hipGraph per episode / eager);
                             the N=1 line reports this path too, under "per_step_launch".
 Every step writes its reward, counters, termination flag, observation, mask and next actions in both.
 
-    python bench.py --gpus 1 --steps 1000 --warmup 200
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...            (no launcher: starts the torch.distributed.run line above itself, as a
+                                             child process, before anything here touches the GPU)
 
 Rank 0 prints ONE JSON line.  Multi-GPU: BASELINE.json's metric is quoted for 4096 envs on the WHOLE node, so
 --gpus N shards those 4096 envs (rank r owns env ids [r*4096/N, (r+1)*4096/N): same seeds, hence same trajectories,
@@ -39,8 +43,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=1000)
-    p.add_argument("--warmup", type=int, default=200)
+    p.add_argument("--steps", type=int, default=20, help="timed bench steps; one step = one whole episode")
+    p.add_argument("--warmup", type=int, default=5, help="untimed episodes first")
     p.add_argument("--envs", type=int, default=4096, help="environments of the whole job (sharded over --gpus)")
     p.add_argument("--nodes", type=int, default=10, help="edge_node_num")
     p.add_argument("--launch", choices=("rollout", "graph", "eager"), default="rollout")
@@ -93,17 +97,14 @@ class Rollout:
             for _ in range(n):
                 self.env.step_random_policy(self.actions, seed=0)
 
-    def run(self, n_steps):
-        """Run exactly n_steps env steps (whole episodes first, then a partial one)."""
-        full, rem = divmod(n_steps, self.T)
-        for _ in range(full):
+    def run(self, n_episodes):
+        """Run exactly n_episodes whole episodes (one bench step each)."""
+        for _ in range(n_episodes):
             if self.graph is not None:
                 self.graph.replay()
             else:
                 self._episode(self.T)
-        if rem:
-            self._episode(rem)
-        self.steps_done += n_steps
+        self.steps_done += n_episodes * self.T
 
 
 def algorithmic_bytes_per_env_step(N, live, draws):
@@ -251,8 +252,9 @@ def ppo_iterations(ns, B, N, iters, rank=0, world=1, trace=lambda m: None):
     med = lambda v: v[len(v) // 2]
     t_tot, t_upd = med(total), med(upd)
     if world > 1:  # the iteration is over when the slowest rank is
+        from marl_amd.utils import dist_utils
         t = th.tensor([t_tot, t_upd], dtype=th.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist_utils.all_reduce_(t, op=dist.ReduceOp.MAX)
         t_tot, t_upd = t.tolist()
     return {"total_ms": 1e3 * t_tot, "update_ms": 1e3 * t_upd, "rollout_ms": 1e3 * (t_tot - t_upd),
             "iters": iters, "envs": B * world, "envs_per_gpu": B, "agents": N, "episode_limit": ns.episode_limit,
@@ -262,18 +264,43 @@ def ppo_iterations(ns, B, N, iters, rank=0, world=1, trace=lambda m: None):
             "rollout_agent_steps_per_s": B * world * N * ns.episode_limit / (t_tot - t_upd)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start the contract's torch.distributed.run line as a
+    CHILD process (nothing in this process has touched the GPU yet, and it never will), pass its output through and
+    exit with its code.  Rank 0 of the child prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # stdout carries the JSON line only: whatever else the ranks print there (gloo's connection notes) goes to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        dst = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+        dst.write(line)
+        dst.flush()
+    return proc.wait()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     import torch as th
     import torch.distributed as dist
     from marl_amd.envs.edge_computing.multihop.edge_computing_env import BatchedEdgeComputingEnv
+    from marl_amd.utils import dist_utils
     from tests.util import make_args
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (a.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if a.rehearse:
         local = 0
     th.cuda.set_device(local)
@@ -309,7 +336,7 @@ def main():
             th.cuda.synchronize(dev)
 
     def timed(envs_per_rank):
-        """W untimed + K timed steps of envs_per_rank envs on every rank; max over ranks"""
+        """W untimed + K timed episodes of envs_per_rank envs on every rank; max over ranks"""
         env_ = BatchedEdgeComputingEnv(ns, n_envs=envs_per_rank, env_id_base=rank * envs_per_rank, device=dev)
         roll_ = Rollout(env_, a.launch)
         roll_.run(a.warmup)
@@ -320,7 +347,7 @@ def main():
         dt_ = time.perf_counter() - t0
         if world > 1:
             t = th.tensor([dt_], dtype=th.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist_utils.all_reduce_(t, op=dist.ReduceOp.MAX)
             dt_ = float(t.item())
         st = env_.status()
         if st & ~32:
@@ -333,17 +360,20 @@ def main():
 
     out = None
     if rank == 0:
-        value = world * B * N * a.steps / dt
+        T_ep = env.episode_limit
+        value = world * B * N * T_ep * a.steps / dt
         out = {
             "metric": "env agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64/u32", "data": "synthetic",
-            "config": {"workload": "edge_computing env step, %d envs in all (%d per GPU on %d GPU%s) x %d agents, "
-                                   "task_size_max=6000, uniform-random policy over the avail mask, reset every %d "
-                                   "steps (BASELINE.json configs[%d])"
-                                   % (B * world, B, world, "" if world == 1 else "s", N, env.episode_limit,
+            "config": {"workload": "edge_computing env rollout, %d envs in all (%d per GPU on %d GPU%s) x %d agents, "
+                                   "task_size_max=6000, uniform-random policy over the avail mask; one bench step = "
+                                   "one whole episode for all envs (reset + first observation/actions + %d env steps); "
+                                   "value = envs x agents x %d x steps / time (BASELINE.json configs[%d])"
+                                   % (B * world, B, world, "" if world == 1 else "s", N, T_ep, T_ep,
                                       1 if world == 1 else 2),
                        "envs_total": B * world, "envs_per_gpu": B, "agents": N,
+                       "env_steps_per_bench_step": T_ep, "us_per_env_step": 1e6 * dt / (a.steps * T_ep),
                        "launch": {"rollout": "ec_rollout_random_policy, one launch per episode",
                                   "graph": "ec_step_random_policy per step, hipGraph per episode",
                                   "eager": "ec_step_random_policy per step, eager"}[a.launch],
@@ -397,7 +427,8 @@ def main():
         del roll_w
         if rank == 0:
             out["weak_scaling"] = {"envs_per_gpu": a.envs, "envs_total": a.envs * world,
-                                   "value": world * a.envs * N * a.steps / dt_w, "unit": "agent-steps/s",
+                                   "value": world * a.envs * N * ns.episode_limit * a.steps / dt_w,
+                                   "unit": "agent-steps/s",
                                    "ms_per_step": 1e3 * dt_w / a.steps}
     if a.ppo_iters > 0:
         trace("ppo iterations")
