@@ -42,6 +42,8 @@ constexpr int MT_M = 397;
 constexpr int MT_MIRROR = 96;              // words [0, MT_MIRROR) are repeated after the state (wrap-free reads)
 constexpr int MT_STRIDE = MT_N + MT_MIRROR; // words per stream in memory
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(8)));
+typedef int32_t i32x4u __attribute__((ext_vector_type(4), aligned(4)));  // rows of 4-byte elements: 16-byte stores at any word
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr u32 NEVER = 0xFFFFFFFFu;
 constexpr u32 T16_NEVER = 0xFFFFu;
 constexpr int RB_FAIL = 48;  // draws of the failure stream held in the LDS window (>= KMAX + DMAX; 2*RB_FAIL <= MT_MIRROR)
@@ -2044,12 +2046,27 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
     double bin_qn = 0.0, bin_px2 = 0.0;
     u32 bin_flip = 0;
     u64 cnt_t = 0, cnt_f = 0;
+    // Phase E in its direct form (every env's lanes inside one wave, adjacency rows as bit masks): each main lane writes
+    // its own observation and availability row, the "queue full" flags of its env come from a ballot -- no LDS staging,
+    // no barrier, no cooperative copy loops.  Its per-node constants are requested here as well.
+    const bool obs_direct = d.epw > 0 && d.adj_bits != nullptr && next_avail != nullptr;
+    double o_qthr = 0.0, o_qlen = 1.0;
+    u64 o_adjb = 0;
+    float o_c0 = 0.0f, o_c1 = 0.0f, o_c2 = 0.0f;
     if (L.valid) {
         bin_qn = d.bin_qn[node];
         bin_px2 = d.bin_px2[node];
         bin_flip = d.bin_flip[node];
         cnt_t = d.rng_cnt[lane];
         cnt_f = d.rng_cnt[P + lane];
+        if (obs_direct) {
+            o_qthr = d.qthr[node];
+            o_qlen = d.qlen[node];
+            o_adjb = d.adj_bits[node];
+            o_c0 = d.obs_const[node * 3 + 0];
+            o_c1 = d.obs_const[node * 3 + 1];
+            o_c2 = d.obs_const[node * 3 + 2];
+        }
     }
     if (L.valid) {
         S.rew[tid] = rew;
@@ -2203,8 +2220,66 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
 #ifdef ABL_NO_OBS
     if (false) {
 #else
-    if (next_obs || next_avail) {
+    if (obs_direct) {
 #endif
+        // edge_node.py:109-136,179-197 per lane (see observe_block for the staged form of the same arithmetic)
+        const bool full = L.valid && (double)wq_len >= o_qthr;  // :186-188
+        const u64 ball = __ballot(full);
+        const u64 fullbits = (ball >> ((threadIdx.x & 63u) - (u32)node)) & (N >= 64 ? ~0ull : (1ull << N) - 1ull);
+        if (L.valid) {
+            const u64 room = o_adjb & ~fullbits;  // adjacent (or own) queues with room
+            const u64 amask = has_new ? (room ? room : 1ull << node) : 0ull;  // bits of the actions 0..N-1; idle = !has_new
+            {
+                int32_t* out = next_avail + lane * d.A;
+                int j = 0;
+                for (; j + 4 <= d.A; j += 4) {
+                    i32x4u v;
+                    v.x = (int)((amask >> j) & 1ull);
+                    v.y = (int)((amask >> (j + 1)) & 1ull);
+                    v.z = (int)((amask >> (j + 2)) & 1ull);
+                    v.w = (int)((amask >> (j + 3)) & 1ull);
+                    if (j + 3 >= N) {  // the chunk holds the idle action (index N)
+                        const int idle = has_new ? 0 : 1;
+                        v.x = j == N ? idle : v.x;
+                        v.y = j + 1 == N ? idle : v.y;
+                        v.z = j + 2 == N ? idle : v.z;
+                        v.w = j + 3 == N ? idle : v.w;
+                    }
+                    *reinterpret_cast<i32x4u*>(out + j) = v;
+                }
+                for (; j < d.A; j++) out[j] = j < N ? (int)((amask >> j) & 1ull) : (has_new ? 0 : 1);
+            }
+            if (next_obs) {
+                f32x4u a, b;
+                a.x = o_c0;
+                a.y = o_c1;
+                a.z = o_c2;
+                a.w = (float)ddiv((double)wq_len, o_qlen);
+                b.x = (float)ddiv(wait_sum, d.deadline);
+                b.y = has_new ? (float)ddiv(nnew.size, d.obs_size_norm) : -1.0f;
+                b.z = has_new ? (float)ddiv(nnew.cycles, d.obs_cyc_norm) : -1.0f;
+                b.w = has_new ? 1.0f : -1.0f;  // task_deadline / deadline (edge_node.py:130): the same number over itself
+                float* out = next_obs + lane * 9;
+                *reinterpret_cast<f32x4u*>(out) = a;
+                *reinterpret_cast<f32x4u*>(out + 4) = b;
+                out[8] = has_new ? (float)nnew.hop : 0.0f;
+            }
+            if (pol.next_actions) {
+                // the uniform-random policy's draw for the next step from the mask just written (same generator and row
+                // numbering as ec_random_policy); every env of the handle has taken the same number of steps
+                int act = N;  // no task: idle is the only available action
+                if (has_new) {
+                    const u64 z = policy_hash(pol.seed, pol.counter + (u64)steps_before + 1, (u64)P, (u64)lane);
+                    u64 m = amask;
+                    int pick = (int)(((z >> 32) * (u64)__popcll(m)) >> 32);
+                    while (pick-- > 0) m &= m - 1;  // drop the `pick` lowest set bits
+                    act = __ffsll((unsigned long long)m) - 1;
+                }
+                pol.next_actions[lane] = act;
+                cr.action = act;
+            }
+        }
+    } else if (next_obs || next_avail) {
         // the failure-stream window is dead since the barrier of phase C: reuse it as observation scratch
         u32* s_full = S.fa;
         u32* s_hasnew = s_full + NT;
@@ -2524,6 +2599,10 @@ typedef void (*rollout_mlp_fn)(const EcDev*, MlpRollout, int64_t*, float*, uint8
                                ExpertRollout);
 rollout_mlp_fn pick_rollout_mlp(int k, int D, int A, bool expert) {  // the common shapes only: every instantiation is a full step kernel
     if (k > 4 || A > 64) return nullptr;
+#ifdef EC_DEV_BUILD
+    if (A > 32 || D > 4) return nullptr;
+    return expert ? k_rollout_mlp<4, 4, true, 1> : k_rollout_mlp<4, 4, false, 1>;
+#endif
     if (A > 32)  // 33..64 actions (the 40-node topology of BASELINE configs[4]): in-degree <= 4 only
         return D > 4 ? nullptr : (expert ? k_rollout_mlp<4, 4, true, 2> : k_rollout_mlp<4, 4, false, 2>);
     if (D <= 4) return expert ? k_rollout_mlp<4, 4, true, 1> : k_rollout_mlp<4, 4, false, 1>;
@@ -2535,15 +2614,19 @@ typedef void (*step_fn)(EcDev, const EcDev*, const int64_t*, float*, uint8_t*, i
 template <int KMAX, bool MULTI>
 step_fn pick_step_d(int D) {
     if (D <= 4) return k_step<KMAX, 4, MULTI>;
+#ifndef EC_DEV_BUILD  // (make dev: only the <4, 4> instantiations, a quarter of the compile time while tuning)
     if (D <= 8) return k_step<KMAX, 8, MULTI>;
+#endif
     return nullptr;
 }
 template <bool MULTI>
 step_fn pick_step(int k, int D, int* kmax, int* dmax) {
     *dmax = D <= 4 ? 4 : 8;
     if (k <= 4) return *kmax = 4, pick_step_d<4, MULTI>(D);
+#ifndef EC_DEV_BUILD
     if (k <= 8) return *kmax = 8, pick_step_d<8, MULTI>(D);
     if (k <= 12) return *kmax = 12, pick_step_d<12, MULTI>(D);
+#endif
     return nullptr;
 }
 

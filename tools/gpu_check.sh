@@ -14,7 +14,7 @@ for w in $WHAT; do
 import json; d=json.load(open('$O/bench_$TAG.json'))
 print('value %.4g  us/env-step %.2f  frac %.4f  one-step kernel median %.1f us  ppo %s' % (d['value'], d['config']['us_per_env_step'], d['roofline']['frac'], d['per_step_launch']['kernel_median_us'], {k: round(v, 2) for k, v in d['ppo_iteration'].items() if k.endswith('_ms')}))";;
     rehearse) timeout -k 10 300 python bench.py --gpus 2 --rehearse --steps 5 --warmup 2 --cpu-seconds 0 > $O/rehearse_$TAG.json 2> $O/rehearse_$TAG.err || { tail -5 $O/rehearse_$TAG.err; exit 1; }; python -c "import json; d=json.loads([l for l in open('$O/rehearse_$TAG.json') if l.startswith('{')][-1]); print('rehearse n_gpus', d['n_gpus'], 'value %.4g' % d['value'], 'ppo', d['ppo_iteration']['total_ms'])";;
-    stamps) MARL_AMD_LIB=$PWD/tools/abl/lib_stamps.so timeout -k 10 200 python tools/stamps.py 4096 2>&1 | tail -26 || exit 1;;
-    stampsroll) MARL_AMD_LIB=$PWD/tools/abl/lib_stamps.so STAMPS_ROLLOUT=20 timeout -k 10 200 python tools/stamps.py 4096 2>&1 | tail -14 | head -12 || exit 1;;
+    stamps) MARL_AMD_LIB=$PWD/tools/abl/${STAMPLIB:-lib_dev_stamps.so} timeout -k 10 200 python tools/stamps.py 4096 2>&1 | tail -26 || exit 1;;
+    stampsroll) MARL_AMD_LIB=$PWD/tools/abl/${STAMPLIB:-lib_dev_stamps.so} STAMPS_ROLLOUT=20 timeout -k 10 200 python tools/stamps.py 4096 2>&1 | tail -14 | head -12 || exit 1;;
   esac
 done
