@@ -46,7 +46,7 @@ typedef int32_t i32x4u __attribute__((ext_vector_type(4), aligned(4)));  // rows
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr u32 NEVER = 0xFFFFFFFFu;
 constexpr u32 T16_NEVER = 0xFFFFu;
-constexpr int RB_FAIL = 48;  // draws of the failure stream held in the LDS window (>= KMAX + DMAX; 2*RB_FAIL <= MT_MIRROR)
+constexpr int RB_FAIL = 40;  // draws of the failure stream held in the LDS window (>= KMAX + DMAX; 2*RB_FAIL <= MT_MIRROR)
 constexpr int AHEAD_FAIL = 2 * RB_FAIL;  // words regenerated ahead of the failure cursor at kernel entry
 constexpr int RB_TASK = 4;   // doubles of the task stream staged per refill (binomial + id + size + cycles)
 constexpr int AHEAD_TASK = 2 * RB_TASK;
@@ -961,7 +961,8 @@ struct StepLds {
                      //      its first word reaches d.hot_thr[node] and may fail a test; all other draws fail none
     u32* rc;         // [RC_N][NT] RNG cursors and the producer/consumer hand-off (RC_*)
 };
-enum { RC_FPOS, RC_FAHEAD, RC_TPOS, RC_TAHEAD, RC_FDELTA, RC_TDELTA, RC_DONE, RC_NX, RC_STAGED, RC_N };
+enum { RC_FPOS, RC_FAHEAD, RC_TPOS, RC_TAHEAD, RC_FDELTA, RC_TDELTA, RC_DONE, RC_NX, RC_STAGED, RC_FNEXT, RC_PFPOS, RC_PTPOS,
+       RC_PSTAGED, RC_N };
 __host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int capW) {
     size_t b = 0;
     b += sizeof(double) * ACC_LDS;
@@ -1206,6 +1207,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
     // when the block was launched with more than d.nmain threads (its memory latency then overlaps the main
     // waves' dependent chain), else the main lanes themselves at the same program points.
     const bool has_producers = (int)blockDim.x > d.nmain;
+    const bool obs_direct = d.epw > 0 && d.adj_bits != nullptr && next_avail != nullptr;  // (see phase E)
     const LaneId L = lane_id_main(d);
     const LaneId R = has_producers ? lane_id(d, d.nmain) : L;
     const bool producer_wave = has_producers ? (int)threadIdx.x >= d.nmain : true;  // wave-uniform
@@ -1426,6 +1428,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
     }
     // producer, part 1: this step's task doubles and the failure window, straight from the words regenerated
     // ahead of the cursors during the previous step (per-lane regeneration only if that invariant is absent)
+    u32 prod_tpos = 0;  // the task cursor at the start of this step (producer lanes)
     if (R.valid) {
         const int ri = R.lidx;
         const size_t tl = (size_t)R.lane, fl = (size_t)P + (size_t)R.lane;
@@ -1434,8 +1437,17 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         const u32 fpos = first ? d.rng_pos[fl] : S.rc[RC_FPOS * NT + ri], fah = first ? d.rng_ahead[fl] : S.rc[RC_FAHEAD * NT + ri];
         RngTask pt;
         RngFail pf;
-        const u32 hthr = d.hot_thr[R.node];
-        if (tah >= (u32)AHEAD_TASK && fah >= (u32)AHEAD_FAIL) {
+        prod_tpos = tpos;
+        // a carried step whose early window and task doubles the producer staged during the previous step, behind that
+        // step's barrier of phase C (see there): they are in S.fa / S.tu already
+        const bool pre = !first && obs_direct && has_producers && S.rc[RC_PSTAGED * NT + ri] != 0 &&
+                         S.rc[RC_PFPOS * NT + ri] == fpos && S.rc[RC_PTPOS * NT + ri] == tpos;
+        if (pre && tah >= (u32)AHEAD_TASK && fah >= (u32)AHEAD_FAIL) {
+            S.rc[RC_STAGED * NT + ri] = S.rc[RC_PSTAGED * NT + ri];
+            pt.ahead = tah;
+            pf.ahead = fah;
+        } else if (tah >= (u32)AHEAD_TASK && fah >= (u32)AHEAD_FAIL) {
+            const u32 hthr = d.hot_thr[R.node];
             // the common case: both streams are regenerated far enough; every load is issued before the first
             // word is tempered, so the whole window costs one memory round trip
             const u32* tw = d.mt + tl * MT_STRIDE + tpos;  // wrap-free thanks to the mirror
@@ -1463,16 +1475,21 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
             pt.u3 = mt_to_double(t1.z, t1.w);
             pt.ahead = tah;
             pf.ahead = fah;
+            S.tu[0 * NT + ri] = pt.u0;
+            S.tu[1 * NT + ri] = pt.u1;
+            S.tu[2 * NT + ri] = pt.u2;
+            S.tu[3 * NT + ri] = pt.u3;
         } else {
+            const u32 hthr = d.hot_thr[R.node];
             pt.open(d.mt + tl * MT_STRIDE, tpos, tah);
             pf.open(d.mt + fl * MT_STRIDE, fpos, fah, S.fa + ri, NT, (u32)RB_FAIL);
             S.hot[ri] = pf.hot_mask((u32)RB_FAIL, hthr);
             S.rc[RC_STAGED * NT + ri] = (u32)RB_FAIL | STAGED_FINAL;
+            S.tu[0 * NT + ri] = pt.u0;
+            S.tu[1 * NT + ri] = pt.u1;
+            S.tu[2 * NT + ri] = pt.u2;
+            S.tu[3 * NT + ri] = pt.u3;
         }
-        S.tu[0 * NT + ri] = pt.u0;
-        S.tu[1 * NT + ri] = pt.u1;
-        S.tu[2 * NT + ri] = pt.u2;
-        S.tu[3 * NT + ri] = pt.u3;
         S.rc[RC_FPOS * NT + ri] = fpos;
         S.rc[RC_FAHEAD * NT + ri] = pf.ahead;
         S.rc[RC_TPOS * NT + ri] = tpos;
@@ -2049,7 +2066,6 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
     // Phase E in its direct form (every env's lanes inside one wave, adjacency rows as bit masks): each main lane writes
     // its own observation and availability row, the "queue full" flags of its env come from a ballot -- no LDS staging,
     // no barrier, no cooperative copy loops.  Its per-node constants are requested here as well.
-    const bool obs_direct = d.epw > 0 && d.adj_bits != nullptr && next_avail != nullptr;
     double o_qthr = 0.0, o_qlen = 1.0;
     u64 o_adjb = 0;
     float o_c0 = 0.0f, o_c1 = 0.0f, o_c2 = 0.0f;
@@ -2068,7 +2084,14 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
             o_c2 = d.obs_const[node * 3 + 2];
         }
     }
+    double tu0 = 0.0, tu1 = 0.0, tu2 = 0.0, tu3 = 0.0;
     if (L.valid) {
+        // (the step's task doubles: read ahead of the barrier, behind which the producer may stage the next step's)
+        tu0 = S.tu[0 * NT + tid];
+        tu1 = S.tu[1 * NT + tid];
+        tu2 = S.tu[2 * NT + tid];
+        tu3 = S.tu[3 * NT + tid];
+        S.rc[RC_FNEXT * NT + tid] = mt_wrap(frng.pos + 2 * frng.idx);  // the failure cursor is final
         S.rew[tid] = rew;
         S.ct[tid] = ct;
         S.cnt[0 * NT + tid] = n_fin;
@@ -2100,6 +2123,47 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         if (terminated) terminated[R.env] = step_now >= (u32)d.T ? 1 : 0;  // :139-142
     }
 
+    if (has_producers && obs_direct && !last && R.valid && producer_wave) {
+        // Part 1 of the NEXT step, now: the cursors are final, the failure window is dead (phase E in its direct form
+        // does not borrow it) and the main lanes have taken this step's task doubles, so the memory round trip of the
+        // next early window runs under phases D and E instead of ahead of the next step's first barrier.  The task
+        // cursor moves by one double, or by four when a task arrives (generate_task's binomial on this step's first
+        // double, redone here; a redraw is left to the next step's own part 1, as is a stream not regenerated far enough).
+        const int ri = R.lidx;
+        const double U = S.tu[0 * NT + ri], qn = d.bin_qn[R.node];
+        int X = -1;
+        if (!(U > qn)) X = 0;
+        else if (!(U - qn > d.bin_px2[R.node])) X = 1;
+        u32 staged_word = 0;
+        if (X >= 0) {
+            const u32 arrival = d.bin_flip[R.node] ? 1u - (u32)X : (u32)X;
+            const u32 fposn = S.rc[RC_FNEXT * NT + ri], tposn = mt_wrap(prod_tpos + (arrival ? 8u : 2u));
+            const u32* fw = d.mt + ((size_t)P + (size_t)R.lane) * MT_STRIDE + fposn;  // wrap-free thanks to the mirror
+            const u32* tw = d.mt + (size_t)R.lane * MT_STRIDE + tposn;
+            const u32 hthr = d.hot_thr[R.node];
+            u32x4 fv[RB_EARLY / 2];
+#pragma unroll
+            for (int i = 0; i < RB_EARLY / 2; i++) fv[i] = *reinterpret_cast<const u32x4*>(fw + 4 * i);
+            const u32x4 t0 = *reinterpret_cast<const u32x4*>(tw), t1 = *reinterpret_cast<const u32x4*>(tw + 4);
+            u32 hot16 = 0;
+#pragma unroll
+            for (int i = 0; i < RB_EARLY / 2; i++) {
+                const u32 a0 = mt_temper(fv[i].x) >> 5, a1 = mt_temper(fv[i].z) >> 5;
+                S.fa[(2 * i) * NT + ri] = a0;
+                S.fa[(2 * i + 1) * NT + ri] = a1;
+                hot16 |= (a0 >= hthr ? 1u : 0u) << (2 * i);
+                hot16 |= (a1 >= hthr ? 1u : 0u) << (2 * i + 1);
+            }
+            S.tu[0 * NT + ri] = mt_to_double(t0.x, t0.y);
+            S.tu[1 * NT + ri] = mt_to_double(t0.z, t0.w);
+            S.tu[2 * NT + ri] = mt_to_double(t1.x, t1.y);
+            S.tu[3 * NT + ri] = mt_to_double(t1.z, t1.w);
+            S.rc[RC_PFPOS * NT + ri] = fposn;
+            S.rc[RC_PTPOS * NT + ri] = tposn;
+            staged_word = (u32)RB_EARLY | (hot16 << STAGED_HOT_SHIFT);
+        }
+        S.rc[RC_PSTAGED * NT + ri] = staged_word;
+    }
     EC_STAMP(5);
     // ---------------------------------------------------------------- phase D: generate_task (:127-128) + write-back
     double wait_sum = 0.0;
@@ -2113,8 +2177,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         if (!f_synced) frng.ahead += S.rc[RC_FDELTA * NT + tid];
         RngTask trng;
         trng.attach(d.mt + (size_t)lane * MT_STRIDE, S.rc[RC_TPOS * NT + tid],
-                    S.rc[RC_TAHEAD * NT + tid] + S.rc[RC_TDELTA * NT + tid], S.tu[0 * NT + tid], S.tu[1 * NT + tid],
-                    S.tu[2 * NT + tid], S.tu[3 * NT + tid]);
+                    S.rc[RC_TAHEAD * NT + tid] + S.rc[RC_TDELTA * NT + tid], tu0, tu1, tu2, tu3);
         generate_task(d, lane, bin_qn, bin_px2, bin_flip, trng, buf, n_off, has_new, nnew);
         for (u32 j = 0; j < wq_len; j++) {
             const u32 pos = (wq_h + j) & wmask;
