@@ -113,6 +113,7 @@ struct alignas(16) EcDev {
     int nmain;     // main threads per k_step block; threads beyond them are the RNG producer lanes
     int dl_ticks;  // (int)(deadline / mini_time_slot): starting point of the deadline searches
     FastDiv divN, divA;
+    int fast_dl;   // the host has checked the bound behind Lut::deadline_ticks' closed form (see build())
     int64_t B, P;
     // scalars
     double dt, inv_dt, deadline;
@@ -307,11 +308,30 @@ struct Lut {
     }
     // smallest n >= 1 such that task_time with the free timer at n ticks exceeds the deadline, and that
     // task_time.  which = 0: free timer is ewt (cet = 0);  which = 1: free timer is cet (ewt fixed).
+    //
+    // Closed form (d.fast_dl): every timer is its tick count times dt up to rounding, so a task_time of K ticks in all
+    // is K * dt up to a bound E the host has evaluated for this LUT (build()): it cannot exceed the deadline for
+    // K <= dl_ticks - 1 and must exceed it for K >= dl_ticks + 2, whatever the split over the five timers.  Only the
+    // free-timer values with K = dl_ticks or dl_ticks + 1 need the fp64 sum: no search loop.
     __device__ __forceinline__ u32 deadline_ticks(int which, u32 ewt, u32 twt, u32 ctt, u32 bwt, double* tt_out) const {
         const u32 others = twt + ctt + bwt + (which ? ewt : 0u);
+        const double tail0 = at(twt), tail1 = at(ctt), tail2 = at(bwt), fixed = which ? at(ewt) : 0.0;
+        if (d.fast_dl) {
+            const int nlo = d.dl_ticks - (int)others;
+            const u32 c0 = nlo < 1 ? 1u : (u32)nlo;  // (c0 + 2 <= dl_ticks + 2 <= maxTicks: checked by the host)
+            double tt[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const double a = at(c0 + j);
+                const double head = which ? dadd(fixed, a) : dadd(a, 0.0);
+                tt[j] = dadd(dadd(dadd(head, tail0), tail1), tail2);
+            }
+            const bool h0 = tt[0] > d.deadline, h1 = tt[1] > d.deadline;
+            *tt_out = h0 ? tt[0] : (h1 ? tt[1] : tt[2]);
+            return h0 ? c0 : (h1 ? c0 + 1 : c0 + 2);
+        }
         const int nominal = d.dl_ticks - (int)others - 1;
         u32 n = nominal < 1 ? 1u : (u32)nominal;
-        const double tail0 = at(twt), tail1 = at(ctt), tail2 = at(bwt), fixed = which ? at(ewt) : 0.0;
         while (n <= (u32)d.maxTicks) {
             double a[4], tt[4];
             peek4(n, a);
@@ -1728,12 +1748,23 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
                     wq_len--;
                     wq_dirty = true;
                     const u32 ewt = sat16(c - w.enq, ovf);
-                    double Td;
-                    const u32 dc = lut.deadline_ticks(1, ewt, w.twt, w.ctt, w.bwt, &Td);
-                    // the drop test precedes the completion test (:268,278): a tie is a drop
-                    const bool succ = w.nexec < dc;
-                    const u32 fin = succ ? w.nexec : dc;
-                    const double T = succ ? lut.task_time(ewt, fin, w.twt, w.ctt, w.bwt) : Td;
+                    bool succ;
+                    u32 fin;
+                    double T;
+                    // (closed form, see Lut::deadline_ticks: a task that completes with fewer than dl_ticks ticks on its
+                    // five timers cannot have been dropped on the way -- most admissions)
+                    if (d.fast_dl && (int)(w.nexec + ewt + w.twt + w.ctt + w.bwt) < d.dl_ticks) {
+                        succ = true;
+                        fin = w.nexec;
+                        T = lut.task_time(ewt, fin, w.twt, w.ctt, w.bwt);
+                    } else {
+                        double Td;
+                        const u32 dc = lut.deadline_ticks(1, ewt, w.twt, w.ctt, w.bwt, &Td);
+                        // the drop test precedes the completion test (:268,278): a tie is a drop
+                        succ = w.nexec < dc;
+                        fin = succ ? w.nexec : dc;
+                        T = succ ? lut.task_time(ewt, fin, w.twt, w.ctt, w.bwt) : Td;
+                    }
                     ovf |= w.hop > EXH_HOP ? 1u : 0u;
                     const u32 nf = c + fin - 1, nh = (w.hop & EXH_HOP) | (succ ? EXH_SUCCESS : 0u) | (fin << 16);
 #pragma unroll
@@ -2987,6 +3018,20 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     std::vector<double> acc(d.maxTicks + 1);
     acc[0] = 0.0;
     for (int n = 1; n <= d.maxTicks; n++) acc[n] = acc[n - 1] + cfg->mini_time_slot;  // edge_node.py:216,250,254,316,319
+
+    {   // Lut::deadline_ticks' closed form: |task_time - K dt| <= E for a task_time of K ticks in all, with
+        // E = 5 max_n |acc[n] - n dt| (the five LUT entries) + 4 half-ulps of the largest partial sum (the four additions)
+        long double emax = 0.0L;
+        for (int n = 0; n <= d.maxTicks; n++) {
+            const long double e = fabsl((long double)acc[n] - (long double)n * (long double)cfg->mini_time_slot);
+            emax = e > emax ? e : emax;
+        }
+        const long double vmax = 5.0L * (long double)acc[d.maxTicks];
+        const long double E = 5.0L * emax + 4.0L * vmax * 1.1102230246251565e-16L;
+        const long double dtl = cfg->mini_time_slot, DL = cfg->deadline;
+        d.fast_dl = (d.dl_ticks >= 2 && d.dl_ticks + 2 <= d.maxTicks && (d.dl_ticks - 1) * dtl + E <= DL &&
+                     (d.dl_ticks + 2) * dtl - E > DL && !getenv("MARL_AMD_EC_SEARCH_DL")) ? 1 : 0;
+    }
 
     std::vector<double> cap(N), qlen(N), qthr(N), bqn(N), bpx2(N), rate((size_t)N * N);
     std::vector<u64> thr_exec_m(N), adj_bits(N, 0);
