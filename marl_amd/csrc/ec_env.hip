@@ -114,6 +114,8 @@ struct alignas(16) EcDev {
     int dl_ticks;  // (int)(deadline / mini_time_slot): starting point of the deadline searches
     FastDiv divN, divA;
     int fast_dl;   // the host has checked the bound behind Lut::deadline_ticks' closed form (see build())
+    int acc_words; // 8-byte words of LDS holding the tick LUT: all of it (>= ACC_LDS, 4 entries per word)
+    int pad_;
     int64_t B, P;
     // scalars
     double dt, inv_dt, deadline;
@@ -128,7 +130,6 @@ struct alignas(16) EcDev {
     const u64* thr_exec_m;    // [N] floor(exp(-efr*dt) * 2^53)
     const u32* hot_thr;       // [N] lowest 27-bit first-word threshold of the node's failure tests (execution and every
                               //     in-link): a draw whose first word is below it fails no test (event skipping)
-    const u32* pad_ptr_;      // keeps sizeof(EcDev) a multiple of 16
     const double* qlen;       // [N]
     const double* qthr;       // [N] qlen * rl_queue_coeff
     const float* obs_const;   // [N][3]
@@ -250,12 +251,13 @@ __device__ __forceinline__ void flag(const EcDev& d, u32 bit) { atomicOr(d.statu
 // the roundings accumulate.  The LUT stores, per n, the (small) distance in units in the last place between the two:
 // 2 bytes per entry, so the whole table of an episode sits in LDS (2 KB for 1024 entries) and a lookup is one LDS
 // read, one fp64 multiply and one integer add -- no global memory and no LDS-or-global divergence inside the step.
-// Entries beyond ACC_LDS_N (longer episodes) come from global memory.  An index beyond the LUT is clamped and
-// remembered in `ovf` (reported through the status word by the caller).
+// Longer episodes take more LDS (d.acc_words; every lookup site used to carry an LDS-or-global diamond, ~200
+// instructions of the mini-slot loop).  An index beyond the LUT is clamped and remembered in `ovf` (reported through
+// the status word by the caller).
 typedef const int16_t __attribute__((address_space(3))) * lds_ci16_ptr;
 struct Lut {
     const EcDev& d;
-    lds_ci16_ptr s_acc;  // explicitly LDS: keeps the two loads below from being merged into one flat load
+    lds_ci16_ptr s_acc;  // explicitly LDS
     mutable u32 ovf;
     __device__ __forceinline__ double make(u32 n, int corr) const {
         return __longlong_as_double(__double_as_longlong(dmul((double)n, d.dt)) + (long long)corr);
@@ -263,10 +265,7 @@ struct Lut {
     __device__ __forceinline__ double at(u32 n) const {
         ovf |= n > (u32)d.maxTicks ? 1u : 0u;
         n = n > (u32)d.maxTicks ? (u32)d.maxTicks : n;
-        int c;
-        if (n < (u32)ACC_LDS_N) c = s_acc[n];
-        else c = d.acc[n];
-        return make(n, c);
+        return make(n, s_acc[n]);  // (the whole table is in LDS: d.acc_words)
     }
     // acc[n .. n+3] (indices clamped to the LUT) with the four loads in flight together: the searches below
     // advance four candidates per round trip instead of one
@@ -276,13 +275,8 @@ struct Lut {
         int c[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) i[j] = n + j > mx ? mx : n + j;
-        if (i[3] < (u32)ACC_LDS_N) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) c[j] = s_acc[i[j]];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) c[j] = d.acc[i[j]];
-        }
+        for (int j = 0; j < 4; j++) c[j] = s_acc[i[j]];
 #pragma unroll
         for (int j = 0; j < 4; j++) a[j] = make(i[j], c[j]);
     }
@@ -983,9 +977,9 @@ struct StepLds {
 };
 enum { RC_FPOS, RC_FAHEAD, RC_TPOS, RC_TAHEAD, RC_FDELTA, RC_TDELTA, RC_DONE, RC_NX, RC_STAGED, RC_FNEXT, RC_PFPOS, RC_PTPOS,
        RC_PSTAGED, RC_N };
-__host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int capW) {
+__host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int capW, int acc_words) {
     size_t b = 0;
-    b += sizeof(double) * ACC_LDS;
+    b += sizeof(double) * acc_words;
     b += (size_t)NT * capW * (16 + 8);
     b += (size_t)NT * KMAX * 8;
     b += (size_t)NT * DMAX * (32 + 5 * 4);
@@ -1203,7 +1197,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         unsigned char* p = smem;
         S.wqm = reinterpret_cast<uint4*>(p);     p += (size_t)NT * d.capW * 16;
         S.rqrec = reinterpret_cast<uint4*>(p);   p += (size_t)NT * DMAX * 32;
-        S.acc = reinterpret_cast<u64*>(p);       p += sizeof(u64) * ACC_LDS;
+        S.acc = reinterpret_cast<u64*>(p);       p += sizeof(u64) * d.acc_words;
         S.wqe = reinterpret_cast<double*>(p);    p += (size_t)NT * d.capW * 8;
         S.exC = reinterpret_cast<u64*>(p);       p += (size_t)NT * KMAX * 8;
         S.rew = reinterpret_cast<double*>(p);    p += (size_t)NT * 8;
@@ -1524,6 +1518,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
             const int a = p0 + i * np;
             if (a < ACC_LDS) S.acc[a] = lut_lo[i];
         }
+        for (int a = ACC_LDS + p0; a < d.acc_words; a += np) S.acc[a] = reinterpret_cast<const u64*>(d.acc)[a];  // long episodes
     }
     if (em && first && L.valid) em->s_cnt[tid] = wq_len | (ex_n << 16);
     EC_STAMP_P(11);
@@ -3067,6 +3062,8 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
         size_t n_ent = (size_t)d.maxTicks + 1;
         if (n_ent < (size_t)ACC_LDS_N) n_ent = ACC_LDS_N;
         n_ent = (n_ent + 3) & ~(size_t)3;
+        d.acc_words = (int)(n_ent / 4);
+        d.pad_ = 0;
         std::vector<int16_t> corr(n_ent, 0);
         for (int n = 0; n <= d.maxTicks; n++) {
             const double prod = (double)n * cfg->mini_time_slot;
@@ -3090,7 +3087,6 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
             hot_thr[i] = (u32)(lo >> 26);
         }
         EC_TRY(dev_upload(h, &d.hot_thr, hot_thr));
-        d.pad_ptr_ = nullptr;
     }
     EC_TRY(dev_upload(h, &d.qlen, qlen));
     EC_TRY(dev_upload(h, &d.qthr, qthr));
@@ -3159,7 +3155,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     };
     // rounds: how many times over the launch's blocks exceed what the device holds at once (0: does not fit a block)
     auto geo_fits = [&](const Geo& g, size_t* lds_out, bool* resident, int64_t* rounds) -> int {
-        const size_t lds = step_lds_bytes(g.epb() * N, h->kmax, h->dmax, d.capW);
+        const size_t lds = step_lds_bytes(g.epb() * N, h->kmax, h->dmax, d.capW, d.acc_words);
         *lds_out = lds;
         *resident = false;
         *rounds = 0;
@@ -3225,7 +3221,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     h->envs_per_block = epb;
     h->blocks = (B + epb - 1) / epb;
     h->lds_obs = (size_t)epb * N * (3 * 4 + 9 * 4);
-    h->lds_step = step_lds_bytes(epb * N, h->kmax, h->dmax, d.capW);
+    h->lds_step = step_lds_bytes(epb * N, h->kmax, h->dmax, d.capW, d.acc_words);
     if (h->lds_step > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_step);
     EC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
     EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->step_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
