@@ -2205,13 +2205,19 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         trng.attach(d.mt + (size_t)lane * MT_STRIDE, S.rc[RC_TPOS * NT + tid],
                     S.rc[RC_TAHEAD * NT + tid] + S.rc[RC_TDELTA * NT + tid], tu0, tu1, tu2, tu3);
         generate_task(d, lane, bin_qn, bin_px2, bin_flip, trng, buf, n_off, has_new, nnew);
-        for (u32 j = 0; j < wq_len; j++) {
-            const u32 pos = (wq_h + j) & wmask;
-            const double et = S.wqe[pos * NT + tid];
-            wait_sum = dadd(wait_sum, et);  // get_waiting_time, edge_node.py:99-104
-            if (last && wq_dirty) {
+        for (u32 j0 = 0; j0 < wq_len; j0 += 4) {  // four entries per LDS round trip; the sum stays in queue order
+            double et[4];
+#pragma unroll
+            for (u32 u = 0; u < 4; u++) et[u] = j0 + u < wq_len ? S.wqe[((wq_h + j0 + u) & wmask) * NT + tid] : 0.0;
+#pragma unroll
+            for (u32 u = 0; u < 4; u++)
+                if (j0 + u < wq_len) wait_sum = dadd(wait_sum, et[u]);  // get_waiting_time, edge_node.py:99-104
+        }
+        if (last && wq_dirty) {
+            for (u32 j = 0; j < wq_len; j++) {
+                const u32 pos = (wq_h + j) & wmask;
                 d.wqm[(size_t)j * P + lane] = S.wqm[pos * NT + tid];
-                d.wqe[(size_t)j * P + lane] = et;
+                d.wqe[(size_t)j * P + lane] = S.wqe[pos * NT + tid];
             }
         }
         if (last) {
