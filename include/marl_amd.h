@@ -263,7 +263,8 @@ int ec_diffusion_reward(const float* w1, const float* b1, const float* w2, const
  *       [dW1x 64*(9+n_actions) | dbias_t[0]+dbias_t[1] 64 | dbias_t[1] 64 | dW2 64*64 | db2 64 | dW3 (9+n_actions)*64 |
  *        db3 9+n_actions | dw3sum 64]
  * The chain rule to the module's own parameters (spectral norm, embeddings) is the caller's: a few 64x64 operations.
- * 9+n_actions <= 64 and, with grads, != 32 and != 64 (the backward uses one spare input column). */
+ * 9+n_actions <= 64 (with 32 or 64 the first layer's gradient tile has no spare input column for the per-t bias sums; the
+ * t = 1 share is then summed from the kernel's delta tile). */
 int ec_diffusion_grad(const float* w1, int32_t ld1, const float* bias_t, const float* w2, const float* b2, const float* w3,
                       const float* b3, const float* w3sum, const float* obs, const int64_t* actions, const uint8_t* t,
                       const float* noise, const float* coef, int64_t rows, int32_t n_actions, int32_t hidden,
@@ -280,6 +281,19 @@ int ec_diffusion_grad_bce(const float* w1, int32_t ld1, const float* bias_t, con
                           const uint8_t* t, const float* noise, const float* other_loss, int32_t side, int32_t label,
                           float scale, int64_t rows, int32_t n_actions, int32_t hidden, float r1_lambda, float* loss,
                           float* grads, void* stream);
+
+/* DGAIL reward from the diffusion discriminator, second half: replaces the agent-condition compute_loss call and the D_phi /
+ * reward arithmetic of DGAILAgent._compute_rewards (dgail_agent.py:486-499, 514-516).  Arguments as ec_diffusion_grad for
+ * condition c = 0 with the weights THAT call reads (the reference runs one spectral-norm power iteration per call);
+ * loss_expert [rows] is the condition-1 loss of the same rows (ec_diffusion_grad, loss only, with that call's weights).
+ *   loss_agent [rows] (optional) <- this call's per-row loss ln
+ *   reward [rows] <- -log(1 - D + 1e-8) * weight + env_coef * env_reward[r],  D = e^-lp / (e^-lp + e^-ln + 1e-8)
+ *   (env_reward may be NULL).  One evaluation per condition: ec_diffusion_reward evaluates both conditions per call. */
+int ec_diffusion_reward_from_loss(const float* w1, int32_t ld1, const float* bias_t, const float* w2, const float* b2,
+                                  const float* w3, const float* b3, const float* w3sum, const float* obs,
+                                  const int64_t* actions, const uint8_t* t, const float* noise, const float* loss_expert,
+                                  const float* env_reward, float weight, float env_coef, int64_t rows, int32_t n_actions,
+                                  int32_t hidden, float r1_lambda, float* loss_agent, float* reward, void* stream);
 
 /* --- rollout bookkeeping ----------------------------------------------------------------------------------------
  * One launch per env step instead of ~20 torch launches: replaces EpisodeBuffer.insert (buffer/episode_buffer.py:21-28)
@@ -377,6 +391,11 @@ int ec_ppo_critic_grad(const float* w1, const float* b1, const float* w2, const 
  * (F.cross_entropy of the behaviour-cloning term, dgail_agent.py:255-262); old_logp / adv / eps_clip / entropy_coef
  * are not read. */
 #define EC_PPO_NLL 4
+/* flags & EC_PPO_FIRST_EPOCH: epoch 0 of ppo_agent.py:96-141 -- the parameters are still the ones the rollout acted with,
+ * so the "old" log-prob of a row is this pass's own (ratio = exp(0) = 1 exactly, as the reference's first epoch computes
+ * it): old_logp must be NULL, adv and logp are required, and logp [rows] receives the log-probs the later epochs pass
+ * back as old_logp.  Saves the forward-only launch that would produce them. */
+#define EC_PPO_FIRST_EPOCH 8
 int ec_ppo_actor_grad_ex(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                          const float* b3, const float* obs, const int32_t* avail, const int64_t* actions,
                          const float* old_logp, const float* adv, const float* mask, int64_t rows, int32_t n_agents,

@@ -159,6 +159,7 @@ def lib():
     L.ec_diffusion_reward.argtypes = [vp] * 14 + [i64, i32, i32, f32, vp, vp, vp, vp, vp]
     L.ec_diffusion_grad.argtypes = [vp, i32] + [vp] * 11 + [i64, i32, i32, f32, vp, vp, vp]
     L.ec_diffusion_grad_bce.argtypes = [vp, i32] + [vp] * 11 + [i32, i32, f32, i64, i32, i32, f32, vp, vp, vp]
+    L.ec_diffusion_reward_from_loss.argtypes = [vp, i32] + [vp] * 12 + [f32, f32, i64, i32, i32, f32, vp, vp, vp]
     L.ec_ppo_actor_grad.argtypes = [vp] * 12 + [i64, i32, i32, i32, f32, f32, f32, vp, vp, vp, vp, vp]
     L.ec_ppo_critic_grad.argtypes = [vp] * 9 + [i64, i32, i32, f32, vp, vp, vp, vp]
     L.ec_ppo_actor_grad_ex.argtypes = [vp] * 12 + [i64, i32, i32, i32, f32, f32, f32, vp, vp, vp, vp, vp, i32, vp]
@@ -189,7 +190,8 @@ def lib():
                "ec_policy_forward", "ec_gail_reward", "ec_diffusion_reward", "ec_diffusion_grad", "ec_expert_policy",
                "ec_ppo_actor_grad", "ec_ppo_critic_grad", "ec_ppo_actor_grad_ex", "ec_ppo_critic_grad_ex", "ec_gail_disc_grad", "ec_store_transition", "ec_bn_relu_dropout_fwd", "ec_bn_relu_dropout_bwd_sums", "ec_bn_relu_dropout_bwd_dx", "ec_expert_mix", "ec_store_episode", "ec_store_episode_static",
                "ec_step_random_policy", "ec_rollout_random_policy", "ec_rollout_mlp_policy",
-               "ec_rollout_mlp_expert_policy", "ec_expert_append_episode", "ec_adam_clip_step", "ec_bn_col_stats", "ec_diffusion_grad_bce", "ec_linear_wgrad", "ec_bn_finalize", "ec_bn_bwd_coeffs", "ec_linear_fwd", "ec_linear_fwd_bn", "ec_disc_rows", "ec_linear_fwd_stats"):
+               "ec_rollout_mlp_expert_policy", "ec_expert_append_episode", "ec_adam_clip_step", "ec_bn_col_stats", "ec_diffusion_grad_bce", "ec_linear_wgrad", "ec_bn_finalize", "ec_bn_bwd_coeffs", "ec_linear_fwd", "ec_linear_fwd_bn", "ec_disc_rows", "ec_linear_fwd_stats",
+               "ec_diffusion_reward_from_loss"):
         getattr(L, fn).restype = C.c_int
     L.ec_last_error.restype = C.c_char_p
     L.ec_version.restype = C.c_char_p

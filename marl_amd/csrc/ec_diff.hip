@@ -45,6 +45,13 @@ struct DiffArgs {
     int side, label;
     float bce_scale;     // 1 / rows (x the data-parallel weight)
     float* grads;     // [dW1x H*SA | dbias(t=0)+dbias(t=1) H | dbias(t=1) H | dW2 H*H | db2 H | dW3 SA*H | db3 SA | dw3sum H]
+    // ec_diffusion_reward_from_loss (forward only): this call is the agent-condition loss ln of dgail_agent.py:487-499 and
+    // rw_lp [R] the expert-condition loss of the same rows; rw_out[r] = -log(1 - D + 1e-8) * rw_weight + rw_env_coef * rw_env[r]
+    // with D = e^-lp / (e^-lp + e^-ln + 1e-8)
+    const float* rw_lp;
+    const float* rw_env;
+    float rw_weight, rw_env_coef;
+    float* rw_out;
 };
 
 template <int TX, bool BWD>
@@ -87,6 +94,7 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
     // persistent gradient accumulators of this wave
     f32x16 gW1[2][TX], gW2[2][2], gW3[TX][2], gw3s[2];
     float gb1[2] = {0.0f, 0.0f}, gb2[2] = {0.0f, 0.0f}, gb3[TX];
+    float gbt[2] = {0.0f, 0.0f};  // dbias(t=1) when the first layer's gradient tile has no spare column (SA == 32 TX)
     if (BWD) {
 #pragma unroll
         for (int a = 0; a < 2; a++) {
@@ -189,7 +197,15 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
         r1 += __shfl_xor(r1, 32);
         const float L = mse + r1 * p.lambda;
         if (ok && half == 0 && p.loss_out) p.loss_out[row] = L;
-        if (!BWD) continue;
+        if (!BWD) {
+            if (p.rw_out && ok && half == 0) {
+                const float pe = expf(-p.rw_lp[row]), pa = expf(-L);
+                const float dphi = pe / (pe + pa + 1e-8f);
+                const float base = -logf(1.0f - dphi + 1e-8f);  // dgail_agent.py:497-499
+                p.rw_out[row] = base * p.rw_weight + (p.rw_env ? p.rw_env_coef * p.rw_env[row] : 0.0f);
+            }
+            continue;
+        }
         if (p.other) {
             const float lp = p.side == 0 ? L : other, ln = p.side == 0 ? other : L;
             const float ea = expf(-lp), eb = expf(-ln), s = ea + eb + 1e-8f, pr = ea / s;
@@ -272,6 +288,17 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
             Ta[in * TSTR + jrow] = in < SA ? s_x[jrow * SAp + in] : (in == SA ? (float)tr : 0.0f);
         wave_sync();
         wgrad<2, TX, 4, TX == 1>(gW1, gb1, Td, Ta, lane);
+        if (SA == 32 * TX) {  // no spare column: the t = 1 rows' share of the bias sum straight from the d1 tile
+            const unsigned tmask = (unsigned)__ballot(tr != 0);  // (both halves hold the same 32 rows)
+#pragma unroll 4
+            for (int s = 0; s < 16; s++) {
+                const int r_ = 2 * s + half;
+                if ((tmask >> r_) & 1u) {
+                    gbt[0] += Td[jrow * TSTR + r_];
+                    gbt[1] += Td[(32 + jrow) * TSTR + r_];
+                }
+            }
+        }
     }
 
     if (BWD && nw > 1) {  // wave 0 collects the block's sums and is the only one to flush them (see block_sum)
@@ -282,8 +309,10 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
         block_sum(ws, lds, wave, nw, lane);
         gw3s[0] = ws[0][0];
         gw3s[1] = ws[0][1];
-        float sc[6] = {gb1[0], gb1[1], gb2[0], gb2[1], gb3[0], TX > 1 ? gb3[TX - 1] : 0.0f};
+        float sc[8] = {gb1[0], gb1[1], gb2[0], gb2[1], gb3[0], TX > 1 ? gb3[TX - 1] : 0.0f, gbt[0], gbt[1]};
         block_sum_scalars(sc, lds, wave, nw, lane);
+        gbt[0] = sc[6];
+        gbt[1] = sc[7];
         gb1[0] = sc[0];
         gb1[1] = sc[1];
         gb2[0] = sc[2];
@@ -317,6 +346,7 @@ __global__ void __launch_bounds__(256) k_diff(DiffArgs p) {
         for (int to = 0; to < 2; to++) {
             atomicAdd(gbp + 32 * to + jrow, gb1[to]);
             atomicAdd(gb2p + 32 * to + jrow, gb2[to]);
+            if (SA == 32 * TX) atomicAdd(gb1p + 32 * to + jrow, gbt[to]);
         }
 #pragma unroll
         for (int to = 0; to < TX; to++)
@@ -348,7 +378,7 @@ int launch_diff(const DiffArgs& a, hipStream_t stream) {
     const int SA = OBS + a.A;
     int nw = 4;
     size_t lds = diff_lds_bytes(TX, SA, nw, BWD);
-    for (int w = 3; w >= 2 && lds > DIFF_LDS_MAX; w--) {  // fewer waves per block until the per-wave tiles fit
+    for (int w = 3; w >= 1 && lds > DIFF_LDS_MAX; w--) {  // fewer waves per block until the per-wave tiles fit
         nw = w;
         lds = diff_lds_bytes(TX, SA, nw, BWD);
     }
@@ -372,7 +402,9 @@ static int diffusion_grad_impl(const char* what, const float* w1, int32_t ld1, c
                                const float* b2, const float* w3, const float* b3, const float* w3sum, const float* obs,
                                const int64_t* actions, const uint8_t* t, const float* noise, const float* coef,
                                const float* other, int side, int label, float bce_scale, int64_t rows, int32_t n_actions,
-                               int32_t hidden, float r1_lambda, float* loss, float* grads, void* stream) {
+                               int32_t hidden, float r1_lambda, float* loss, float* grads, void* stream,
+                               const float* rw_lp = nullptr, const float* rw_env = nullptr, float rw_weight = 0.0f,
+                               float rw_env_coef = 0.0f, float* rw_out = nullptr) {
     if (rows == 0) return EC_OK;
     if (rows < 0) return ec::fail(EC_EINVAL, "%s: rows < 0", what);
     if (!w1 || !bias_t || !w2 || !b2 || !w3 || !b3 || !w3sum || !obs || !actions || !t || !noise)
@@ -382,11 +414,11 @@ static int diffusion_grad_impl(const char* what, const float* w1, int32_t ld1, c
     if (n_actions < 1 || SA > 64) return ec::fail(EC_EINVAL, "%s: obs+actions = %d exceeds 64", what, SA);
     if (ld1 < SA) return ec::fail(EC_EINVAL, "%s: ld1 %d < obs+actions %d", what, ld1, SA);
     if (grads && !coef && !other) return ec::fail(EC_EINVAL, "%s: grads without a coefficient", what);
-    if (!grads && !loss) return ec::fail(EC_EINVAL, "%s: neither loss nor grads requested", what);
-    // the backward borrows input column SA of the first layer's gradient tile for the per-t bias sums
-    if (grads && (SA == 32 || SA == 64)) return ec::fail(EC_EINVAL, "%s: obs+actions = %d leaves no spare input column", what, SA);
+    if (!grads && !loss && !rw_out) return ec::fail(EC_EINVAL, "%s: neither loss nor grads requested", what);
+    // (the backward borrows input column SA of the first layer's gradient tile for the per-t bias sums; with
+    // obs+actions = 32 or 64 there is none and the t = 1 share is summed from the d1 tile instead)
     DiffArgs a{w1, ld1, bias_t, w2, b2, w3, b3, w3sum, obs, actions, t, noise, coef, rows, n_actions, r1_lambda, loss,
-               other, side, label, bce_scale, grads};
+               other, side, label, bce_scale, grads, rw_lp, rw_env, rw_weight, rw_env_coef, rw_out};
     const int TX = SA <= 32 ? 1 : 2;
     if (grads) return TX == 1 ? launch_diff<1, true>(a, (hipStream_t)stream) : launch_diff<2, true>(a, (hipStream_t)stream);
     return TX == 1 ? launch_diff<1, false>(a, (hipStream_t)stream) : launch_diff<2, false>(a, (hipStream_t)stream);
@@ -410,6 +442,18 @@ int ec_diffusion_grad_bce(const float* w1, int32_t ld1, const float* bias_t, con
         return ec::fail(EC_EINVAL, "ec_diffusion_grad_bce: side %d / label %d must be 0 or 1", side, label);
     return diffusion_grad_impl("ec_diffusion_grad_bce", w1, ld1, bias_t, w2, b2, w3, b3, w3sum, obs, actions, t, noise, nullptr,
                                other_loss, side, label, scale, rows, n_actions, hidden, r1_lambda, loss, grads, stream);
+}
+
+int ec_diffusion_reward_from_loss(const float* w1, int32_t ld1, const float* bias_t, const float* w2, const float* b2,
+                                  const float* w3, const float* b3, const float* w3sum, const float* obs,
+                                  const int64_t* actions, const uint8_t* t, const float* noise, const float* loss_expert,
+                                  const float* env_reward, float weight, float env_coef, int64_t rows, int32_t n_actions,
+                                  int32_t hidden, float r1_lambda, float* loss_agent, float* reward, void* stream) {
+    if (rows != 0 && (!loss_expert || !reward))
+        return ec::fail(EC_EINVAL, "ec_diffusion_reward_from_loss: loss_expert and reward are required");
+    return diffusion_grad_impl("ec_diffusion_reward_from_loss", w1, ld1, bias_t, w2, b2, w3, b3, w3sum, obs, actions, t, noise,
+                               nullptr, nullptr, 0, 0, 0.0f, rows, n_actions, hidden, r1_lambda, loss_agent, nullptr, stream,
+                               loss_expert, env_reward, weight, env_coef, reward);
 }
 
 }  // extern "C"

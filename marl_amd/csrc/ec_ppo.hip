@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
         f.act = (HEAD == 0 && f.ok) ? (int)p.actions[f.trow] : 0;
         f.onehot = (HEAD == 1 && p.onehot && f.ok) ? (int)p.onehot[f.trow] : 0;
         f.olp = (HEAD == 0 && p.old_logp && f.ok) ? p.old_logp[f.trow] : 0.0f;
-        f.adv = (HEAD == 0 && p.old_logp && f.ok) ? p.adv[f.trow] : 0.0f;
+        f.adv = (HEAD == 0 && p.adv && f.ok) ? p.adv[f.trow] : 0.0f;
         f.tgt = (HEAD == 1 && p.target && f.ok) ? p.target[f.trow] : 0.0f;
         f.m = f.ok ? (p.mask ? p.mask[f.trow] : 1.0f) : 0.0f;
         return f;
@@ -332,14 +332,18 @@ __global__ void __launch_bounds__(256) k_ppo(PpoArgs p) {
                 if (p.out_b) p.out_b[row] = Hent;
             }
             const bool nll = (p.flags & EC_PPO_NLL) != 0;
-            if (!p.old_logp && !nll) continue;  // forward only
+            // EC_PPO_FIRST_EPOCH: the parameters are the ones the rollout's log-probs belong to (epoch 0 of
+            // ppo_agent.py:96-141), so old_logp IS this pass's log-prob: ratio = exp(0) = 1, and the pass leaves the
+            // log-probs in out_a for the later epochs instead of a forward-only launch producing them first
+            const bool first_epoch = (p.flags & EC_PPO_FIRST_EPOCH) != 0;
+            if (!p.old_logp && !nll && !first_epoch) continue;  // forward only
             float obj, c1;
             if (nll) {  // F.cross_entropy(logits, actions) = -mean log-prob (dgail_agent.py:255-262)
                 obj = lp_a;
                 c1 = inr_a;
             } else {
                 const float advr = cur.adv;
-                const float ratio = expf(lp_a - cur.olp);
+                const float ratio = expf(lp_a - (first_epoch ? lp_a : cur.olp));
                 const float lo = 1.0f - p.eps_clip, hi = 1.0f + p.eps_clip;
                 const float surr1 = ratio * advr, surr2 = fminf(fmaxf(ratio, lo), hi) * advr;
                 const float inrange = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
@@ -669,8 +673,11 @@ int ec_ppo_actor_grad_ex(const float* w1, const float* b1, const float* w2, cons
     if (int rc = check_common("ec_ppo_actor_grad", need, 8, rows, hidden, n_agents)) return rc;
     if (n_agents < 1) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: n_agents %d", n_agents);
     if (n_actions < 1 || n_actions > 64) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: n_actions %d out of range [1,64]", n_actions);
-    if (old_logp && !adv) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: old_logp without adv");
-    if (grads && !old_logp && !(flags & EC_PPO_NLL)) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: grads without old_logp");
+    if ((old_logp || (flags & EC_PPO_FIRST_EPOCH)) && !adv) return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: old_logp without adv");
+    if ((flags & EC_PPO_FIRST_EPOCH) && (old_logp || !logp))
+        return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: EC_PPO_FIRST_EPOCH takes no old_logp and needs the logp output");
+    if (grads && !old_logp && !(flags & (EC_PPO_NLL | EC_PPO_FIRST_EPOCH)))
+        return ec::fail(EC_EINVAL, "ec_ppo_actor_grad: grads without old_logp");
     PpoArgs a{w1, b1, w2, b2, w3, b3, obs, avail, actions, old_logp, adv, nullptr, mask, rows, n_agents, n_actions,
               eps_clip, entropy_coef, inv_denom, grads, loss, logp, entropy, row_index, flags, nullptr, 0, nullptr, 0};
     const int TO3 = n_actions <= 32 ? 1 : 2, IN1T = OBS + n_agents <= 32 ? 1 : 2;

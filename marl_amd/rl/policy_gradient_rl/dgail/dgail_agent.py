@@ -32,6 +32,7 @@ from marl_amd.utils.action_selectors import greedy_selector, soft_selector
 from marl_amd.utils.advantage_utils import get_gae
 from marl_amd.utils.dist_utils import (all_reduce_grads_, all_reduce_sum_, broadcast_params_, dist_on, global_mean,
                                        global_mean_std, world_size)
+from marl_amd.utils.rl_utils import UnfusedShape
 
 
 class DGAILAgent:
@@ -85,7 +86,6 @@ class DGAILAgent:
         # fused HIP minibatch update of policy / value (ec_ppo_*_grad_ex): every p.grad is a view into one flat buffer
         # per network that the kernels accumulate into, the BC term's autograd adds to, and the DP all-reduce reduces
         self._fg_policy = self._fg_value = self._fg_gail = self._fg_bc = None
-        self._noted_torch_disc = False
         if self._fused_ok() and not getattr(args, "ec_torch_update", False):
             # one buffer for what a minibatch step clears: [policy grads | value grads | BC grads | 2 loss words]
             n_p = sum(p.numel() for p in self.policy.parameters())
@@ -96,9 +96,8 @@ class DGAILAgent:
             self._fg_bc = self._fg_step[n_p + n_v:2 * n_p + n_v]  # the BC term's gradient before its weight
             self._fg_losses = self._fg_step[2 * n_p + n_v:]
             self._fg_gail = ppo_device.FlatGrads(self.gail_discriminator)
-        elif self.device.type == "cuda":
-            print("DGAILAgent: hidden_dim=%s / obs_shape=%s / ec_torch_update: the policy/value update runs on torch "
-                  "autograd, not on the fused HIP kernels" % (args.hidden_dim, self.obs_shape))
+        elif self.device.type == "cuda" and not getattr(args, "ec_torch_update", False):
+            raise UnfusedShape("DGAILAgent", args)
 
     # ------------------------------------------------------------------ acting
     def _fused_ok(self):
@@ -174,14 +173,9 @@ class DGAILAgent:
         kernel applicable, the four compute_loss calls and their backward run on ec_diffusion_grad."""
         if len(self.expert_transitions) < self.args.batch_size_run:
             return 0.0, 0.0, 0.0
-        if (obs is not None and self._fused_ok() and self.state_action_dim not in (32, 64)
-                and not getattr(self.args, "ec_torch_update", False)):
+        if obs is not None and self._fused_ok() and not getattr(self.args, "ec_torch_update", False):
             return self._update_discriminator_fused(obs, actions)
-        if self.device.type == "cuda" and not self._noted_torch_disc:
-            self._noted_torch_disc = True
-            print("DGAILAgent: the diffusion-discriminator update runs on torch autograd, not on ec_diffusion_grad "
-                  "(hidden_dim=%s, obs+actions=%d, ec_torch_update=%s)"
-                  % (self.args.hidden_dim, self.state_action_dim, getattr(self.args, "ec_torch_update", False)))
+        # (reached on the CPU, or with ec_torch_update: the constructor refuses a GPU learner the kernels do not cover)
         if agent_sa is None:
             agent_sa = self._prepare_batch(obs, actions)
         prob_expert = self._d_phi(self._expert_sa(agent_sa.size(0)))
@@ -298,20 +292,15 @@ class DGAILAgent:
             # the (t, noise) draws of the two compute_loss calls (dgail_network.py:90-91), expert condition first
             t_e, n_e = self.rng.diffusion_draws(rows, self.state_action_dim)
             t_a, n_a = self.rng.diffusion_draws(rows, self.state_action_dim)
-            t_e, t_a = t_e.to(th.uint8), t_a.to(th.uint8)
             # The reference never puts the module in eval mode, so each compute_loss call runs one spectral-norm power
             # iteration of its own: the expert loss sees W / sigma after the first iteration, the agent loss after the
-            # second (reading the parametrised weights performs the iteration).  One kernel pass per condition, each
-            # with the weights its call would see.
-            l_e, _, _, _ = mlp_device.diffusion_reward(mlp_device.linear_params(d.mlp), d.time_embed.weight,
-                                                       d.cond_embed.weight, obs_flat, act_flat, self.n_actions, t_e,
-                                                       n_e, t_a, n_a, r1_lambda=d.R1_LAMBDA)
-            _, l_a, _, _ = mlp_device.diffusion_reward(mlp_device.linear_params(d.mlp), d.time_embed.weight,
-                                                       d.cond_embed.weight, obs_flat, act_flat, self.n_actions, t_e,
-                                                       n_e, t_a, n_a, r1_lambda=d.R1_LAMBDA)
-            pe, pa = th.exp(-l_e), th.exp(-l_a)
-            base = -th.log(1.0 - pe / (pe + pa + 1e-8) + 1e-8)  # dgail_agent.py:497-499
-            final = base * weight + 0.02 * env_flat
+            # second (constructing a DiffusionLossCall reads the parametrised weights once, which performs the
+            # iteration).  ONE evaluation per condition, each with the weights its call would see; D_phi, the log and
+            # the env-reward term are formed in the second launch (ec_diffusion_reward_from_loss).
+            call_e = mlp_device.DiffusionLossCall(d, 1, obs_flat, act_flat, self.n_actions, t_e, n_e)
+            l_e = call_e.loss(d.R1_LAMBDA)
+            call_a = mlp_device.DiffusionLossCall(d, 0, obs_flat, act_flat, self.n_actions, t_a, n_a)
+            final, _ = call_a.reward(l_e, weight=weight, env_reward=env_flat, env_coef=0.02, r1_lambda=d.R1_LAMBDA)
         return final.reshape(obs.shape[0], obs.shape[1], obs.shape[2], 1)
 
     def _compute_rewards_torch(self, obs, actions, env_r, use_gail, weight):

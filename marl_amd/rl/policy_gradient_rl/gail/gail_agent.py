@@ -25,6 +25,7 @@ from marl_amd.utils.action_selectors import greedy_selector, soft_selector
 from marl_amd.utils.advantage_utils import get_gae
 from marl_amd.utils.dist_utils import (all_reduce_grads_, all_reduce_sum_, broadcast_params_, global_mean_std,
                                        world_size)
+from marl_amd.utils.rl_utils import UnfusedShape
 
 
 class GAILAgent:
@@ -55,10 +56,8 @@ class GAILAgent:
         if self._fused_ok() and not getattr(args, "ec_torch_update", False):
             self._fg_actor = ppo_device.FlatGrads(self.actor)
             self._fg_critic = ppo_device.FlatGrads(self.critic)
-        elif self.device.type == "cuda":
-            print("GAILAgent: hidden_dim=%s / activate_fun=%s / ec_torch_update=%s: the actor/critic update runs on torch autograd, "
-                  "not on the fused HIP kernels" % (args.hidden_dim, getattr(args, "activate_fun", "relu"),
-                                                    getattr(args, "ec_torch_update", False)))
+        elif self.device.type == "cuda" and not getattr(args, "ec_torch_update", False):
+            raise UnfusedShape("GAILAgent", args)
 
     # ------------------------------------------------------------------ acting
     def _with_ids(self, obs):
@@ -163,7 +162,7 @@ class GAILAgent:
         if a.normalize_rewards:
             mean, std = global_mean_std(rewards)
             rewards = (rewards - mean) / (std + 1e-8)
-        old_logp, _ = ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, want_logp=True)
+        old_logp = None  # (left by the actor's pass of epoch 0, whose parameters are still the rollout's: EC_PPO_FIRST_EPOCH)
         old_v = ppo_device.critic_pass(self.critic, obs, masks, N, want_values=True).view(shape)
         old_next_v = ppo_device.critic_pass(self.critic, next_obs, masks, N, want_values=True).view(shape)
         advantages = get_gae(a, rewards, old_v, old_next_v, masks)
@@ -184,9 +183,12 @@ class GAILAgent:
             self._clip_and_step(self.critic, self.critic_optimizer)
 
             self._fg_actor.zero_()
-            ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, old_logp=old_logp, adv=advantages,
-                                  eps_clip=a.eps_clip, entropy_coef=a.entropy_coef if a.use_entropy else 0.0,
-                                  inv_denom=inv_denom, grads=self._fg_actor.flat, loss=losses[1:2])
+            logp, _ = ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, old_logp=old_logp,
+                                            adv=advantages, eps_clip=a.eps_clip,
+                                            entropy_coef=a.entropy_coef if a.use_entropy else 0.0, inv_denom=inv_denom,
+                                            grads=self._fg_actor.flat, loss=losses[1:2], first_epoch=old_logp is None)
+            if old_logp is None:
+                old_logp = logp
             if n_expert > 0:  # (the BC term is a constant zero while no expert transition is stored, :86-87)
                 # gail_agent.py:85-107: NLL of the expert's actions on 64 sampled transitions (unmasked logits), on the
                 # same kernel with the cross-entropy objective; adds into the actor's flat gradient

@@ -26,6 +26,7 @@ from marl_amd.utils import mlp_device, optim_device, ppo_device
 
 from marl_amd.utils.dist_utils import (all_reduce_grads_, all_reduce_sum_, broadcast_params_, dist_on as _dist_on,
                                        global_mean_std)  # noqa: E402,F401
+from marl_amd.utils.rl_utils import UnfusedShape  # noqa: E402
 
 
 class PPOAgent:
@@ -54,10 +55,8 @@ class PPOAgent:
         if self._fused_policy_ok() and not getattr(args, "ec_torch_update", False):
             self._fg_actor = ppo_device.FlatGrads(self.actor)
             self._fg_critic = ppo_device.FlatGrads(self.critic)
-        elif self.device.type == "cuda":
-            print("PPOAgent: hidden_dim=%s / activate_fun=%s / ec_torch_update=%s: the actor/critic update runs on torch autograd, "
-                  "not on the fused HIP kernels" % (args.hidden_dim, getattr(args, "activate_fun", "relu"),
-                                                    getattr(args, "ec_torch_update", False)))
+        elif self.device.type == "cuda" and not getattr(args, "ec_torch_update", False):
+            raise UnfusedShape("PPOAgent", args)
 
     def _with_ids(self, obs):
         ids = self._eye.expand(*obs.shape[:-2], -1, -1)
@@ -104,7 +103,9 @@ class PPOAgent:
         if a.normalize_rewards:
             mean, std = global_mean_std(rewards)
             rewards = (rewards - mean) / (std + 1e-5)
-        old_logp, _ = ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, want_logp=True)
+        # (old log-probs, ppo_agent.py:96: left by the actor's pass of epoch 0, whose parameters are still the rollout's --
+        # no forward-only launch for them)
+        old_logp = None
         old_v = ppo_device.critic_pass(self.critic, obs, masks, N, want_values=True).view(shape)
         if shape[1] > 1 and getattr(self.buffer, "next_obs_is_shifted_obs", False):
             # the runner's transition store filed one observation as next_obs[t] and obs[t+1] (it says so on the
@@ -136,9 +137,12 @@ class PPOAgent:
             self.critic_lr_scheduler.step()
 
             self._fg_actor.zero_()
-            ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, old_logp=old_logp, adv=advantages,
-                                  eps_clip=a.eps_clip, entropy_coef=a.entropy_coef if a.use_entropy else 0.0,
-                                  inv_denom=inv_denom, grads=self._fg_actor.flat, loss=losses[1:2])
+            logp, _ = ppo_device.actor_pass(self.actor, obs, avail_actions, actions, masks, N, old_logp=old_logp,
+                                            adv=advantages, eps_clip=a.eps_clip,
+                                            entropy_coef=a.entropy_coef if a.use_entropy else 0.0, inv_denom=inv_denom,
+                                            grads=self._fg_actor.flat, loss=losses[1:2], first_epoch=old_logp is None)
+            if old_logp is None:
+                old_logp = logp
             all_reduce_sum_(self._fg_actor.flat)
             self._clip_and_step(self.actor, self.actor_optimizer)
             self.actor_lr_scheduler.step()

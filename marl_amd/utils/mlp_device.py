@@ -180,6 +180,29 @@ class DiffusionLossCall:
         self._launch(None, out, None, r1_lambda)
         return out
 
+    def reward(self, loss_expert, weight=1.0, env_reward=None, env_coef=0.0, r1_lambda=1e-4, want_loss=False):
+        """This call being the agent-condition loss ln of dgail_agent.py:487-499 and `loss_expert` [rows] the
+        expert-condition loss lp of the same rows: -log(1 - D_phi + 1e-8) * weight + env_coef * env_reward, formed in the
+        kernel that evaluates ln (ec_diffusion_reward_from_loss).  Returns (reward [rows], ln [rows] | None)."""
+        loss_expert = _f32(loss_expert, "loss_expert").reshape(-1)
+        if loss_expert.shape[0] != self.rows:
+            raise ValueError("loss_expert rows mismatch")
+        if env_reward is not None:
+            env_reward = _f32(env_reward, "env_reward").reshape(-1)
+            if env_reward.shape[0] != self.rows:
+                raise ValueError("env_reward rows mismatch")
+        dev = self.obs.device
+        out = th.empty((self.rows,), dtype=th.float32, device=dev)
+        ln = th.empty((self.rows,), dtype=th.float32, device=dev) if want_loss else None
+        w1, bias_t, w2, b2, w3, b3, w3sum = self._dev
+        with th.cuda.device(dev):
+            _abi.check(_abi.lib().ec_diffusion_reward_from_loss(
+                _p(w1), int(w1.shape[1]), _p(bias_t), _p(w2), _p(b2), _p(w3), _p(b3), _p(w3sum), _p(self.obs),
+                _p(self.actions), _p(self.t), _p(self.noise), _p(loss_expert), _p(env_reward), C.c_float(weight),
+                C.c_float(env_coef), self.rows, int(self.n_actions), int(self.H), C.c_float(r1_lambda), _p(ln), _p(out),
+                _stream(dev)), "ec_diffusion_reward_from_loss")
+        return out, ln
+
     def backward(self, coef, r1_lambda=1e-4):
         """coef [rows] = d objective / d loss[r].  Returns (tensors, gradients) for torch.autograd.backward."""
         SA, H = self.SA, self.H

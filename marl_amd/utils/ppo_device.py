@@ -44,6 +44,7 @@ def _rows(obs):
 EC_PPO_LOGITS = 1
 EC_PPO_GATHERED = 2
 EC_PPO_NLL = 4
+EC_PPO_FIRST_EPOCH = 8
 
 
 def _index(row_index, dev):
@@ -56,14 +57,16 @@ def _index(row_index, dev):
 
 def actor_pass(actor, obs, avail, actions, mask, n_agents, old_logp=None, adv=None, eps_clip=0.2, entropy_coef=0.0,
                inv_denom=1.0, grads=None, loss=None, want_logp=False, want_entropy=False, row_index=None, logits=False,
-               gathered=False, nll=False):
+               gathered=False, nll=False, first_epoch=False):
     """One launch.  Forward only when old_logp is None (returns logp / entropy); with old_logp and adv it accumulates
     the loss into `loss` [1] and, if `grads` (flat, parameter order) is given, the gradient into it.
     row_index [r] (optional): the pass takes rows row_index[0..r) of the per-row tables (a shuffled minibatch), outputs
     are in pass order; avail / mask may be None (no action mask / all ones); logits=True: Categorical(logits=...).
     gathered=True: the tables ARE the minibatch (gathered by the caller); row_index only names each row's agent.
     nll=True: the objective is the log-prob of `actions` (loss = -inv_denom * sum mask * logp: a cross-entropy term);
-    old_logp / adv are not needed."""
+    old_logp / adv are not needed.
+    first_epoch=True (with adv, no old_logp): the pass of the update's epoch 0 -- the old log-probs are this pass's own
+    (ratio 1); returns them as logp for the later epochs (EC_PPO_FIRST_EPOCH)."""
     w1, b1, w2, b2, w3, b3 = linear_params(actor)
     obs, table_rows = _rows(obs)
     dev = obs.device
@@ -75,7 +78,10 @@ def actor_pass(actor, obs, avail, actions, mask, n_agents, old_logp=None, adv=No
         mask = _f32(mask, "mask").reshape(-1)
     if old_logp is not None:
         old_logp = _f32(old_logp, "old_logp").reshape(-1)
+    if adv is not None:
         adv = _f32(adv, "adv").reshape(-1)
+    if first_epoch:
+        want_logp = True
     for t in (avail, actions, mask, old_logp, adv):
         if t is not None and t.shape[0] != table_rows:
             raise ValueError("rows mismatch")
@@ -92,7 +98,7 @@ def actor_pass(actor, obs, avail, actions, mask, n_agents, old_logp=None, adv=No
                                                    C.c_float(entropy_coef), C.c_float(inv_denom), _p(grads), _p(loss),
                                                    _p(logp), _p(ent), _p(row_index),
                                                    (EC_PPO_LOGITS if logits else 0) | (EC_PPO_GATHERED if gathered else 0)
-                                                   | (EC_PPO_NLL if nll else 0),
+                                                   | (EC_PPO_NLL if nll else 0) | (EC_PPO_FIRST_EPOCH if first_epoch else 0),
                                                    _stream(dev)), "ec_ppo_actor_grad_ex")
     return logp, ent
 

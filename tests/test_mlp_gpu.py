@@ -273,11 +273,13 @@ def test_reference_fixtures(N):
 
 
 @pytest.mark.parametrize("n_actions,rows,c,train", [(11, 1, 1, False), (11, 1000, 1, False), (11, 40960, 0, True),
-                                                    (41, 3000, 0, False), (41, 3000, 1, True), (3, 333, 1, False)])
+                                                    (41, 3000, 0, False), (41, 3000, 1, True), (3, 333, 1, False),
+                                                    (23, 2500, 1, True), (23, 70, 0, False), (55, 2100, 0, True)])
 def test_diffusion_grad(n_actions, rows, c, train):
     """ec_diffusion_grad (one compute_loss call with its backward, dgail_network.py:82-108 + dgail_agent.py:229-233)
     against fp64 torch autograd of the same module — per-row losses and every parameter gradient, through the
-    spectral norm (train=True: with the power iteration the reference's forward performs) and both embeddings."""
+    spectral norm (train=True: with the power iteration the reference's forward performs) and both embeddings.
+    n_actions = 23 / 55: obs+actions = 32 / 64, where the first layer's gradient tile has no spare column for t."""
     from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import DiffusionDiscriminator
     from marl_amd.utils import mlp_device
     dev = _dev()
@@ -361,11 +363,49 @@ def test_diffusion_grad_rejects():
     from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import DiffusionDiscriminator
     from marl_amd.utils import mlp_device
     dev = _dev()
-    n_actions, rows = 23, 64  # 9 + 23 = 32: no spare input column for the per-t bias sums
+    n_actions, rows = 11, 64
     net = DiffusionDiscriminator(9 + n_actions, 64).to(dev)
     call = mlp_device.DiffusionLossCall(net, 1, th.zeros(rows, 9, device=dev), th.zeros(rows, dtype=th.long, device=dev),
                                         n_actions, th.zeros(rows, dtype=th.long, device=dev),
                                         th.zeros(rows, 9 + n_actions, device=dev))
-    assert call.loss().shape == (rows,)  # the forward has no such limit
-    with pytest.raises(_abi.EcError, match="spare input column"):
-        call.backward(th.zeros(rows, device=dev))
+    assert call.loss().shape == (rows,)
+    flat = th.zeros(20000, device=dev)
+    with pytest.raises(_abi.EcError, match="without a coefficient"):
+        call._launch(None, None, flat, 1e-4)
+    with pytest.raises(ValueError, match="rows mismatch"):
+        call.backward(th.zeros(rows + 1, device=dev))
+
+
+@pytest.mark.parametrize("n_actions,rows", [(11, 1), (11, 4097), (41, 3000), (23, 500)])
+def test_diffusion_reward_from_loss(n_actions, rows):
+    """ec_diffusion_reward_from_loss (the agent-condition pass with D_phi, the log and the env-reward term in its
+    epilogue; dgail_agent.py:486-499, 514-516): its ln is the plain forward launch's bit for bit, and the reward is the
+    reference's formula on (lp, ln) -- also against ec_diffusion_reward, which evaluates both conditions in one call."""
+    from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import DiffusionDiscriminator
+    from marl_amd.utils import mlp_device
+    dev = _dev()
+    SA = 9 + n_actions
+    th.manual_seed(3 + n_actions)
+    net = DiffusionDiscriminator(SA, 64).eval().to(dev)  # eval: both paths read the same weights
+    gen = th.Generator().manual_seed(rows)
+    obs = _obs(rows, gen).to(dev)
+    actions = th.randint(0, n_actions, (rows,), generator=gen).to(dev)
+    env_r = th.randn(rows, generator=gen).to(dev)
+    draws = [(th.randint(0, 2, (rows,), generator=gen).to(dev), th.randn(rows, SA, generator=gen).to(dev)) for _ in range(2)]
+    call_e = mlp_device.DiffusionLossCall(net, 1, obs, actions, n_actions, *draws[0])
+    call_a = mlp_device.DiffusionLossCall(net, 0, obs, actions, n_actions, *draws[1])
+    lp, ln = call_e.loss(net.R1_LAMBDA), call_a.loss(net.R1_LAMBDA)
+    got, got_ln = call_a.reward(lp, weight=0.83, env_reward=env_r, env_coef=0.02, r1_lambda=net.R1_LAMBDA, want_loss=True)
+    assert th.equal(got_ln, ln)
+    pe, pa = th.exp(-lp.double()), th.exp(-ln.double())
+    dphi = pe / (pe + pa + 1e-8)
+    want = -th.log(1.0 - dphi + 1e-8) * 0.83 + 0.02 * env_r.double()
+    well = (dphi > 1e-3) & (dphi < 0.99)   # (where fp32 resolves 1 - D_phi, as in test_reference_fixtures)
+    _close(got[well], want[well], "reward", rtol=2e-4, atol=1e-5)
+    no_env, _ = call_a.reward(lp, weight=0.83, r1_lambda=net.R1_LAMBDA)
+    _close((got - no_env)[well], (0.02 * env_r.double())[well], "env term", rtol=1e-3, atol=1e-5)
+    Le, La, _, _ = mlp_device.diffusion_reward(mlp_device.linear_params(net.mlp), net.time_embed.weight, net.cond_embed.weight,
+                                               obs, actions, n_actions, draws[0][0], draws[0][1], draws[1][0], draws[1][1],
+                                               r1_lambda=net.R1_LAMBDA)
+    _close(lp, Le, "lp vs ec_diffusion_reward", rtol=1e-4, atol=1e-6)
+    _close(ln, La, "ln vs ec_diffusion_reward", rtol=1e-4, atol=1e-6)

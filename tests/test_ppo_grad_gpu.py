@@ -97,6 +97,45 @@ def test_actor_loss_and_gradients(N, rows):
     assert th.equal(lp2, lp)
 
 
+@pytest.mark.parametrize("N,rows", [(10, 33), (10, 100000), (40, 7777)])
+def test_actor_first_epoch_pass_equals_pass_on_forward_logp(N, rows):
+    """EC_PPO_FIRST_EPOCH (epoch 0 of ppo_agent.py:96-141: the old log-probs are the pass's own, ratio 1): the same loss
+    and gradient bits as a pass fed the forward-only launch's log-probs, and it returns those log-probs."""
+    from marl_amd.utils import ppo_device
+    dev = th.device("cuda:0")
+    actor, _ = _nets(N, 5 + N)
+    actor = actor.to(dev)
+    obs, avail, actions, adv, mask, _ = [t.to(dev) for t in _batch(N, rows, rows + 1)]
+    denom = float(max(mask.sum(), 1.0))
+    old_logp, _ = ppo_device.actor_pass(actor, obs, avail, actions, mask, N, want_logp=True)
+    fg = ppo_device.FlatGrads(actor)
+    out = []
+    for first in (False, True):
+        fg.zero_()
+        loss = th.zeros(1, device=dev)
+        lp, _ = ppo_device.actor_pass(actor, obs, avail, actions, mask, N, old_logp=None if first else old_logp, adv=adv,
+                                      eps_clip=0.2, entropy_coef=0.01, inv_denom=1.0 / denom, grads=fg.flat, loss=loss,
+                                      first_epoch=first, want_logp=True)
+        out.append((fg.flat.clone(), loss.clone(), lp))
+    assert th.equal(out[1][2], old_logp)
+    assert th.equal(out[0][0], out[1][0]) and th.equal(out[0][1], out[1][1])
+    assert float(out[1][0].abs().max()) > 0
+
+
+def test_first_epoch_flag_is_checked():
+    from marl_amd import _abi
+    from marl_amd.utils import ppo_device
+    dev = th.device("cuda:0")
+    actor, _ = _nets(10, 1)
+    actor = actor.to(dev)
+    obs, avail, actions, adv, mask, _ = [t.to(dev) for t in _batch(10, 64, 2)]
+    fg = ppo_device.FlatGrads(actor)
+    with pytest.raises(_abi.EcError, match="old_logp without adv"):
+        ppo_device.actor_pass(actor, obs, avail, actions, mask, 10, grads=fg.flat, first_epoch=True)
+    with pytest.raises(_abi.EcError, match="takes no old_logp"):
+        ppo_device.actor_pass(actor, obs, avail, actions, mask, 10, old_logp=adv, adv=adv, grads=fg.flat, first_epoch=True)
+
+
 @pytest.mark.parametrize("N,rows", [(10, 1), (10, 64), (10, 100000), (40, 7777)])
 def test_critic_loss_and_gradients(N, rows):
     from marl_amd.utils import ppo_device

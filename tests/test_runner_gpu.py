@@ -739,3 +739,16 @@ def test_guided_rollout_entry_points_reject_bad_arguments():
     assert L.ec_adam_clip_step(5, n5, null, null, null, null, null, null, null, null, null, null, null, null, null) != 0
     assert b"networks" in L.ec_last_error()
     env.close()
+
+
+@pytest.mark.parametrize("kind", ["ppo", "gail", "dgail"])
+def test_unfused_shapes_raise_unless_torch_update_is_asked_for(kind):
+    """A GPU learner whose shape the fused update kernels do not cover (hidden_dim != 64) must not slide onto the
+    torch-autograd formulation silently (10x slower): it raises, naming --ec_torch_update, and runs when that is set."""
+    from marl_amd.agent_register import agent_register
+    from marl_amd.utils.rl_utils import UnfusedShape
+    make = (lambda **kw: _args(4, **kw)) if kind == "ppo" else (lambda **kw: _imitation_args(kind, 4, **kw))
+    with pytest.raises(UnfusedShape, match="ec_torch_update"):
+        agent_register[kind](make(hidden_dim=128))
+    agent = agent_register[kind](make(hidden_dim=128, ec_torch_update=1))
+    assert agent.device.type == "cuda"
