@@ -101,21 +101,36 @@ class ExpertTransitions:
                                                     C.c_void_p(th.cuda.current_stream(self.device).cuda_stream)),
                        "ec_expert_append_episode")
 
-    def sample_transitions(self, n, size=None):
-        """n distinct transitions, uniformly (np.random.choice(len, n, replace=False) of the reference):
-        returns obs [n,N,O], actions [n,N].  `size`: len(self) when the caller already has it (len() synchronises)."""
-        size = len(self) if size is None else int(size)
-        n = min(int(n), size)
-        idx = self.rng.choice_without_replacement(size, n)
-        return self.obs[idx], self.actions[idx]
+    def _share(self, obs, actions):
+        """data parallel: every rank takes rank 0's sample (the update is then the one-process update whatever
+        the number of ranks; the stores differ per rank, so the rows travel, not their indices)"""
+        from marl_amd.utils.dist_utils import broadcast_, dist_on
+        if dist_on():
+            obs, actions = obs.contiguous(), actions.contiguous()
+            broadcast_(obs, 0)
+            broadcast_(actions, 0)
+        return obs, actions
 
-    def sample_transitions_many(self, n, count):
+    def sample_transitions(self, n, size=None, shared=False):
+        """n distinct transitions, uniformly (np.random.choice(len, n, replace=False) of the reference):
+        returns obs [n,N,O], actions [n,N].  `size`: len(self) when the caller already has it (len() synchronises).
+        shared: under torch.distributed every rank gets rank 0's sample (n is cut to the smallest store)."""
+        from marl_amd.utils.dist_utils import dist_on
+        size = len(self) if size is None else int(size)
+        n = min(int(n), self.global_len() if (shared and dist_on()) else size)
+        idx = self.rng.choice_without_replacement(size, n)
+        out = self.obs[idx], self.actions[idx]
+        return self._share(*out) if shared else out
+
+    def sample_transitions_many(self, n, count, shared=False):
         """`count` consecutive sample_transitions(n) draws in one go: obs [count,n,N,O], actions [count,n,N] (one size
         query, one batched draw, one gather)."""
+        from marl_amd.utils.dist_utils import dist_on
         size = len(self)
-        n = min(int(n), size)
+        n = min(int(n), self.global_len() if (shared and dist_on()) else size)
         idx = self.rng.choice_without_replacement_many(size, n, int(count))
-        return self.obs[idx], self.actions[idx]
+        out = self.obs[idx], self.actions[idx]
+        return self._share(*out) if shared else out
 
     def sample_rows(self, n):
         """n agent-rows with replacement over the concatenation of all stored transitions

@@ -134,7 +134,7 @@ class DGAILAgent:
     def _compute_bc_loss(self, sample=None):
         """dgail_agent.py:151-168: cross entropy on `batch_expert_transitions` random expert transitions."""
         obs, act = sample if sample is not None else self.expert_transitions.sample_transitions(
-            self.args.batch_expert_transitions)
+            self.args.batch_expert_transitions, shared=True)
         logits = self.policy(self._with_ids(obs).reshape(-1, self.policy_input_dim))
         return F.nll_loss(F.log_softmax(logits, dim=-1), act.reshape(-1), reduction="mean")
 
@@ -359,7 +359,7 @@ class DGAILAgent:
         for _ in range(a.ppo_epochs):
             perm = self.rng.permutation(rows)
             # the epoch's BC samples in one batched draw (same draws, same order as one per minibatch step)
-            bc_obs, bc_act = self.expert_transitions.sample_transitions_many(a.batch_expert_transitions, n_mb)
+            bc_obs, bc_act = self.expert_transitions.sample_transitions_many(a.batch_expert_transitions, n_mb, shared=True)
             for i in range(n_mb):
                 idx = perm[i * mb:(i + 1) * mb]
                 bc = (bc_obs[i], bc_act[i])
@@ -402,7 +402,7 @@ class DGAILAgent:
         for _ in range(a.ppo_epochs):
             perm = self.rng.permutation(rows)
             # the epoch's BC samples in one batched draw (same draws, same order as one per minibatch step)
-            bc_obs, bc_act = self.expert_transitions.sample_transitions_many(a.batch_expert_transitions, n_mb)
+            bc_obs, bc_act = self.expert_transitions.sample_transitions_many(a.batch_expert_transitions, n_mb, shared=True)
             for i in range(n_mb):
                 idx = perm[i * mb:(i + 1) * mb]
                 bc = (bc_obs[i], bc_act[i])
@@ -582,7 +582,7 @@ class DGAILAgent:
     def _bc_pretrain(self):
         """dgail_agent.py:520-534: `_bc_pretrain_steps` Adam(1e-3) steps, one random expert transition each."""
         for _ in range(self._bc_pretrain_steps):
-            obs_e, act_e = self.expert_transitions.sample_transitions(1)
+            obs_e, act_e = self.expert_transitions.sample_transitions(1, shared=True)
             logits = self.policy(self._with_ids(obs_e).reshape(-1, self.policy_input_dim))
             loss = F.cross_entropy(logits, act_e.reshape(-1))
             self._bc_optimizer.zero_grad()

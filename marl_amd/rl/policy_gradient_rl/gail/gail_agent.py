@@ -6,7 +6,9 @@ transitions labelled 0), rewards  -log sigmoid(x) + log sigmoid(-x)  from the up
 mode: batch-norm batch statistics and dropout are active, as in the reference), then PPO with the reference's
 normalisation constants (1e-8), the clipped surrogate + entropy, and a behaviour-cloning term whose weight follows
 the success-rate schedule of :118-126.  Acting uses the fused policy kernel; GAE the HIP scan.  Data parallel as
-PPOAgent (flat gradient all-reduce, global normalisation statistics); batch-norm statistics stay per rank.
+PPOAgent (flat gradient all-reduce, global normalisation statistics); the discriminator's BatchNorm statistics are the whole job's (the ranks'
+moments are merged before every layer's normalisation and in its backward), and the expert samples of an update are
+rank 0's, broadcast: 2 ranks x B/2 envs make the same update as 1 rank x B envs.
 """
 import os
 
@@ -106,7 +108,7 @@ class GAILAgent:
         """gail_agent.py:85-107: NLL of the expert's actions on 64 sampled expert transitions (unmasked logits)."""
         if len(self.expert_transitions) == 0:
             return th.tensor(0.0, device=self.device)
-        e_obs, e_act = self.expert_transitions.sample_transitions(64)
+        e_obs, e_act = self.expert_transitions.sample_transitions(64, shared=True)
         log_probs = F.log_softmax(self.actor(self._with_ids(e_obs)), dim=-1)
         return F.nll_loss(log_probs.view(-1, self.args.n_actions), e_act.view(-1), reduction="mean")
 
@@ -127,7 +129,7 @@ class GAILAgent:
         """gail_agent.py:131-172: returns the GAIL rewards [B,T,N,1] of the rollout (obs without the agent ids)."""
         a = self.args
         B, T, N = obs.shape[0], obs.shape[1], obs.shape[2]
-        e_obs, e_act = self.expert_transitions.sample_transitions(64)
+        e_obs, e_act = self.expert_transitions.sample_transitions(64, shared=True)
         expert_logits = self.discriminator(self._with_ids(e_obs), F.one_hot(e_act, num_classes=a.n_actions).float())
         # the agent rows (obs | id | one-hot action), built once for the training pass and the reward pass below
         if obs.is_cuda and obs.dtype == th.float32 and actions.dtype == th.int64:
@@ -137,7 +139,9 @@ class GAILAgent:
             onehot = F.one_hot(actions.squeeze(-1), num_classes=a.n_actions).float()
             agent_rows = self.discriminator.rows(obs_id.reshape(-1, obs_id.size(-1)), onehot.reshape(-1, onehot.size(-1)))
             del obs_id, onehot
-        agent_logits = self.discriminator.forward_rows(agent_rows)
+        # (data parallel: the rollout rows are spread over the ranks; BatchNorm statistics over all of them, as the
+        # reference's one process has them -- the 64 expert rows are the same on every rank and keep their own)
+        agent_logits = self.discriminator.forward_rows(agent_rows, sync=True)
         bce = nn.BCEWithLogitsLoss()
         loss = bce(agent_logits.reshape(-1, 1), th.ones_like(agent_logits.reshape(-1, 1))) + \
             bce(expert_logits, th.zeros_like(expert_logits))
@@ -146,7 +150,7 @@ class GAILAgent:
         all_reduce_grads_(list(self.discriminator.parameters()), average=True)
         self._clip_and_step(self.discriminator, self.discriminator_optimizer)
         with th.no_grad():
-            x = self.discriminator.forward_rows(agent_rows).reshape(B, T, N, 1)
+            x = self.discriminator.forward_rows(agent_rows, sync=True).reshape(B, T, N, 1)
             rewards = -F.logsigmoid(x) + F.logsigmoid(-x)
         self.last_losses["discriminator_loss"] = loss.detach()
         return rewards
@@ -192,7 +196,7 @@ class GAILAgent:
             if n_expert > 0:  # (the BC term is a constant zero while no expert transition is stored, :86-87)
                 # gail_agent.py:85-107: NLL of the expert's actions on 64 sampled transitions (unmasked logits), on the
                 # same kernel with the cross-entropy objective; adds into the actor's flat gradient
-                e_obs, e_act = self.expert_transitions.sample_transitions(64, size=n_expert)
+                e_obs, e_act = self.expert_transitions.sample_transitions(64, size=n_expert, shared=True)
                 ppo_device.actor_pass(self.actor, e_obs, None, e_act, None, N, grads=self._fg_actor.flat, logits=True,
                                       nll=True, inv_denom=self.bc_loss_weight / (e_act.numel() * world_size()))
             all_reduce_sum_(self._fg_actor.flat)

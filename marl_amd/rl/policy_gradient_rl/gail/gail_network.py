@@ -6,6 +6,7 @@ import torch.nn.functional as F
 
 from marl_amd.rl.policy_gradient_rl.dgail.dgail_network import SplitKLinear
 from marl_amd.utils import linear_device
+from marl_amd.utils.dist_utils import all_reduce_sum_, dist_on
 
 _ACT = {"relu": F.relu, "tanh": th.tanh, "leaky_relu": F.leaky_relu}
 
@@ -78,6 +79,47 @@ class _TallBatchNormFn(th.autograd.Function):
         return dx, s2, s1, None
 
 
+class _SyncBatchNormFn(th.autograd.Function):
+    """Training-mode BatchNorm1d over the rows of EVERY rank (data parallel: each rank holds a shard of the rollout and the
+    reference normalises over the whole of it, gail_network.py:97-125).  Forward: the ranks' (n, sum x) and then their
+    sums of squared deviations about the global mean are all-reduced.  Backward: as torch's SyncBatchNorm -- dx uses the
+    all-reduced sums of dy and dy * x (so that, after the learner's gradient AVERAGE over ranks, everything upstream
+    carries the gradient of the ranks' mean loss), the layer's own weight / bias gradients stay the local sums."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        stat = th.cat([th.full((1,), float(x.shape[0]), dtype=th.float64, device=x.device), x.double().sum(0)])
+        all_reduce_sum_(stat)
+        n = stat[0]
+        mean = (stat[1:] / n).to(x.dtype)
+        m2 = ((x - mean) ** 2).double().sum(0)
+        all_reduce_sum_(m2)
+        var = (m2 / n).to(x.dtype)
+        invstd = th.rsqrt(var + eps)
+        scale = invstd * weight
+        y = th.addcmul(bias - mean * scale, x, scale)
+        ctx.save_for_backward(x, weight, mean, invstd)
+        ctx.n = float(n)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dmean, _dvar):
+        x, weight, mean, invstd = ctx.saved_tensors
+        n = ctx.n
+        s1_l = dy.sum(0)
+        s2_l = (dy * x).sum(0)
+        glob = th.stack([s1_l, s2_l]).double()
+        all_reduce_sum_(glob)
+        s1, s2 = glob[0].to(x.dtype), glob[1].to(x.dtype)
+        s2 = (s2 - mean * s1) * invstd                 # sum over all ranks of dy * xhat
+        a = weight * invstd
+        b = -a * invstd * s2 / n
+        c = -a * s1 / n - b * mean
+        dx = th.addcmul(th.addcmul(c, dy, a), x, b)
+        return dx, (s2_l - mean * s1_l) * invstd, s1_l, None
+
+
 def _keep_mask(x, p):
     """bool [rows, C]: bernoulli(1 - p) per element, drawn in row chunks (no [rows, C] fp32 temporary)"""
     keep = th.empty(x.shape, dtype=th.bool, device=x.device)
@@ -148,7 +190,7 @@ def _draw_seed():
     return int(th.empty((), dtype=th.int64).random_())
 
 
-def _bn_batch_stats(x, weight, bias, eps, running, partials=None, pivot=None):
+def _bn_batch_stats(x, weight, bias, eps, running, partials=None, pivot=None, sync=False):
     """mean, var, invstd, scale, shift [C] of a training-mode BatchNorm over x [rows, C] (fp32, on the device), and the
     module's running statistics updated: one streaming pass (ec_bn_col_stats; torch.var_mean's column reduction runs at
     a third of the HBM rate) leaving per-block partial sums about the pivot row x[0], then ec_bn_finalize, which adds
@@ -156,7 +198,10 @@ def _bn_batch_stats(x, weight, bias, eps, running, partials=None, pivot=None):
     running: (running_mean, running_var, num_batches_tracked, momentum or None) or None; updated through raw pointers
     (autograd does not see the buffers change).
     partials [n, 2, C] with pivot [C]: the statistics pass was already done by the kernel that wrote x (ec_linear_fwd_bn's
-    sums of (x - pivot) and (x - pivot)^2); only ec_bn_finalize runs."""
+    sums of (x - pivot) and (x - pivot)^2); only ec_bn_finalize runs.
+    sync (data parallel): the statistics are the whole job's -- every rank turns its partial sums into (n, mean, sum of
+    squared deviations) in float64, the ranks' moments are merged (Chan's formula, two small all-reduces: the pivots
+    differ per rank, so the partial sums themselves cannot be added), and the per-column tail runs as torch ops."""
     import ctypes as C
 
     from marl_amd import _abi
@@ -175,6 +220,32 @@ def _bn_batch_stats(x, weight, bias, eps, running, partials=None, pivot=None):
     rm, rv, nbt, momentum = running if running is not None else (None, None, None, 0.0)
     if nbt is not None:
         nbt.data += 1  # (before the launch: momentum=None weighs this batch 1 / count)
+    if sync and dist_on():
+        with th.cuda.device(x.device):
+            if not have:
+                _abi.check(_abi.lib().ec_bn_col_stats(ptr(x), rows, Cc, n_part, ptr(partials), stream), "ec_bn_col_stats")
+        with th.no_grad():
+            s = partials.double().sum(0)                                  # [2, C] about this rank's pivot
+            k = pivot.reshape(-1, Cc)[0].double() if pivot.dim() > 1 else pivot.double()
+            m_r = k + s[0] / rows
+            m2_r = s[1] - s[0] * s[0] / rows
+            stat = th.cat([th.full((1,), float(rows), dtype=th.float64, device=x.device), m_r * rows])
+            all_reduce_sum_(stat)
+            n = stat[0]
+            g_mean = stat[1:] / n
+            m2 = m2_r + rows * (m_r - g_mean) ** 2
+            all_reduce_sum_(m2)
+            g_var = (m2 / n).clamp_(min=0)
+            mean.copy_(g_mean)
+            var.copy_(g_var)
+            invstd.copy_(th.rsqrt(var + eps))
+            scale.copy_(invstd * weight)
+            shift.copy_(bias - mean * scale)
+            if rm is not None and rv is not None:
+                mo = float(momentum) if momentum is not None else 1.0 / float(nbt)
+                rm.data.mul_(1 - mo).add_(mean, alpha=mo)
+                rv.data.mul_(1 - mo).add_((g_var * (n / (n - 1).clamp(min=1))).float(), alpha=mo)
+        return mean, var, invstd, scale, shift
     with th.cuda.device(x.device):
         if not have:
             _abi.check(_abi.lib().ec_bn_col_stats(ptr(x), rows, Cc, n_part, ptr(partials), stream), "ec_bn_col_stats")
@@ -198,7 +269,7 @@ class _BnReluDropHipFn(th.autograd.Function):
         return vp, (vp(x), vp(scale), vp(shift), vp(mask), C.c_uint64(seed), C.c_float(p))
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, p, running=None, stats=None):
+    def forward(ctx, x, weight, bias, eps, p, running=None, stats=None, sync=False):
         """running: (running_mean, running_var, num_batches_tracked, momentum or None) of the module, updated in the
         same launch that finalises the statistics (through raw pointers: autograd does not see the buffers change)"""
         import ctypes as C
@@ -208,7 +279,7 @@ class _BnReluDropHipFn(th.autograd.Function):
         rows, Cc = x.shape
         stream = C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)
         # (stats: (partials, pivot) left by the kernel that wrote x, ec_linear_fwd_stats -- no statistics pass here then)
-        mean, var, invstd, scale, shift = _bn_batch_stats(x, weight, bias, eps, running, *(stats or ()))
+        mean, var, invstd, scale, shift = _bn_batch_stats(x, weight, bias, eps, running, *(stats or (None, None)), sync=sync)
         mask = _explicit_mask(x, p)
         if mask is not None:
             mask = mask.to(device=x.device, dtype=th.uint8).contiguous()
@@ -219,6 +290,7 @@ class _BnReluDropHipFn(th.autograd.Function):
             _abi.check(_abi.lib().ec_bn_relu_dropout_fwd(*head, rows, Cc, vp(out), stream), "ec_bn_relu_dropout_fwd")
         ctx.save_for_backward(x, weight, mean, invstd, scale, shift, mask)
         ctx.seed, ctx.p = seed, p
+        ctx.sync = bool(sync) and dist_on()
         ctx.mark_non_differentiable(mean, var)
         return out, mean, var
 
@@ -242,10 +314,23 @@ class _BnReluDropHipFn(th.autograd.Function):
             a, b, c, s2, s1 = cols.unbind(0)
             _abi.check(_abi.lib().ec_bn_bwd_coeffs(vp(partials), n_part, vp(mean), vp(invstd), vp(weight), rows, Cc, vp(a), vp(b),
                                                    vp(c), vp(s2), vp(s1), stream), "ec_bn_bwd_coeffs")
+            if ctx.sync:
+                # data parallel (see _SyncBatchNormFn): dx from the sums over every rank's rows; the layer's own weight /
+                # bias gradients (s2, s1 above) stay this rank's
+                glob = th.cat([partials.double().sum(0).reshape(-1),
+                               th.full((1,), float(rows), dtype=th.float64, device=x.device)])
+                all_reduce_sum_(glob)
+                n = glob[-1]
+                t1, t2 = glob[:Cc].float(), glob[Cc:2 * Cc].float()
+                g2 = (t2 - mean * t1) * invstd
+                a = weight * invstd
+                b = -a * invstd * g2 / n
+                c = (-a * t1 / n - b * mean).float().contiguous()
+                a, b = a.float().contiguous(), b.float().contiguous()
             dx = th.empty_like(x)
             _abi.check(_abi.lib().ec_bn_relu_dropout_bwd_dx(vp(dout), *head, vp(a), vp(b), vp(c), rows, Cc, vp(dx), stream),
                        "ec_bn_relu_dropout_bwd_dx")
-        return dx, s2, s1, None, None, None, None
+        return dx, s2, s1, None, None, None, None, None
 
 
 class TallBatchNorm1d(nn.BatchNorm1d):
@@ -254,7 +339,12 @@ class TallBatchNorm1d(nn.BatchNorm1d):
 
     TALL_NUMEL = 1 << 30
 
-    def forward(self, x):
+    def forward(self, x, sync=False):
+        if sync and dist_on() and self.training:   # statistics over every rank's rows (data parallel)
+            y, mean, var = _SyncBatchNormFn.apply(x, self.weight, self.bias, self.eps)
+            n = th.tensor([float(x.shape[0])], dtype=th.float64, device=x.device)
+            self._track(int(all_reduce_sum_(n).item()), mean, var)
+            return y
         if not self.tall(x):
             return super().forward(x)
         y, mean, var = _TallBatchNormFn.apply(x, self.weight, self.bias, self.eps)
@@ -270,14 +360,15 @@ class TallBatchNorm1d(nn.BatchNorm1d):
         C = self.num_features
         return self.training and C % 4 == 0 and C <= 256 and 256 % (C // 4) == 0 and self.weight is not None
 
-    def relu_dropout(self, x, p, stats=None):
+    def relu_dropout(self, x, p, stats=None, sync=False):
         """dropout(relu(self(x)), p) for a training-mode input, as one autograd node (HIP kernels on the device);
-        stats: (partials, pivot) of x's column sums when the kernel that wrote x left them"""
+        stats: (partials, pivot) of x's column sums when the kernel that wrote x left them; sync: batch statistics over
+        every rank's rows (data parallel)"""
         if self.hip_ok(x):
             running = None
             if self.track_running_stats:  # updated by the kernel that finalises the statistics
                 running = (self.running_mean, self.running_var, self.num_batches_tracked, self.momentum)
-            y, _, _ = _BnReluDropHipFn.apply(x, self.weight, self.bias, self.eps, float(p), running, stats)
+            y, _, _ = _BnReluDropHipFn.apply(x, self.weight, self.bias, self.eps, float(p), running, stats, sync)
             return y
         y, mean, var = _TallBnReluDropFn.apply(x, self.weight, self.bias, self.eps, float(p))
         self._track(x.shape[0], mean, var)
@@ -342,7 +433,7 @@ class Discriminator(nn.Module):
                 return False
         return True
 
-    def _forward_rows_fused_tails(self, x):
+    def _forward_rows_fused_tails(self, x, sync=False):
         """forward_rows for a no-grad pass in training mode (gail_agent.py:165-167, the reward pass): per layer the
         statistics pass over the Linear's output, then BatchNorm -> ReLU -> Dropout applied inside the NEXT Linear's
         kernel, with the draws (one seed per layer, in layer order) the two-step path would make"""
@@ -357,7 +448,7 @@ class Discriminator(nn.Module):
             if bn.track_running_stats:
                 running = (bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum)
             x = x.contiguous()
-            _, _, _, scale, shift = _bn_batch_stats(x, bn.weight, bn.bias, bn.eps, running, partials, pivot)
+            _, _, _, scale, shift = _bn_batch_stats(x, bn.weight, bn.bias, bn.eps, running, partials, pivot, sync=sync)
             # (the kernel that writes layer i + 1's pre-activations also leaves their column sums for bn(i + 1), about
             # the layer's bias as the pivot: its inputs are normalised activations, so the outputs stay within a few
             # standard deviations of the bias and the one-pass variance does not cancel)
@@ -366,19 +457,23 @@ class Discriminator(nn.Module):
             x, partials, pivot = (out[0], out[1], nxt.bias.detach()) if want else (out, None, None)
         return x
 
-    def forward_rows(self, x):
-        """logits [rows, 1] of input rows as `rows` builds them"""
+    def forward_rows(self, x, sync=False):
+        """logits [rows, 1] of input rows as `rows` builds them.  sync: the rows are this rank's shard of a batch spread
+        over the ranks of a data-parallel job, and every BatchNorm takes its statistics over the whole of it (the
+        reference normalises over the whole rollout, gail_network.py:97-125); no effect without a process group."""
+        sync = bool(sync) and dist_on()
         if self._fused_tails_ok(x):
-            return self._forward_rows_fused_tails(x)
+            return self._forward_rows_fused_tails(x, sync)
         for i in (1, 2, 3):
             stats = []   # (the layer's kernel leaves the column sums of its output where it is the HIP one)
             x = getattr(self, "fc%d" % i)(x, stats)
             bn, drop = getattr(self, "bn%d" % i), getattr(self, "dropout%d" % i)
-            if (bn.hip_ok(x) or bn.tall(x)) and drop.training and 0.0 <= drop.p < 1.0 and self.activate_func is F.relu:
+            if ((bn.hip_ok(x) or (bn.tall(x) and not sync)) and drop.training and 0.0 <= drop.p < 1.0
+                    and self.activate_func is F.relu):
                 # one autograd node for the layer's tail (memory at 10^7..10^8 rows)
-                x = bn.relu_dropout(x, drop.p, stats[0] if stats else None)
+                x = bn.relu_dropout(x, drop.p, stats[0] if stats else None, sync)
                 continue
-            if x.shape[0] > 1:
-                x = bn(x)
+            if x.shape[0] > 1 or sync:
+                x = bn(x, sync) if sync else bn(x)
             x = drop(self.activate_func(x))
         return self.fc4(x)

@@ -91,3 +91,57 @@ def test_ppo_data_parallel_nccl_world2():
     assert (diff <= 0.02 * budget + 1e-7).mean() >= 0.99 and diff.max() <= 1.05 * a.lr, (float(diff.max()), budget)
     for k in losses1:
         assert abs(got[0][2][k] - losses1[k]) < 1e-4 * max(1.0, abs(losses1[k]))
+
+
+# ---------------------------------------------------------------------------------------------- GAIL / DGAIL (product path)
+# The assertion of tests/test_dp_imitation_cpu.py on the HIP kernels: 2 ranks x B/2 environments == 1 rank x B environments
+# for GAILAgent.train() (whole-job BatchNorm statistics through _bn_batch_stats(sync) / _BnReluDropHipFn) and
+# DGAILAgent.train() (fused diffusion / GAIL-discriminator / minibatch policy steps run eagerly under a process group).
+# Two forms: `gloo` with both ranks on cuda:0 (runs on the one-GPU box: same product code, host-staged reductions) and
+# `nccl` on two GPUs (skipped below two devices).
+def _imitation_worker(rank, world, port, q, kind, backend):
+    import torch.distributed as dist
+    from tests.test_dp_imitation_cpu import train_once
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = rank if backend == "nccl" else 0
+    th.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=th.device("cuda:%d" % dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, train_once(kind, rank, world, device="cuda")))
+    finally:
+        dist.destroy_process_group()
+
+
+def _imitation_world2(kind, backend):
+    from tests.test_dp_imitation_cpu import compare, imitation_args, train_once, BG
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_imitation_worker, args=(r, 2, port, q, kind, backend)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    single = train_once(kind, 0, 1, device="cuda")
+    a = imitation_args(kind, BG, "cuda")
+    lrs = ({"actor": a.lr, "critic": a.lr, "discriminator": a.lr} if kind == "gail" else
+           {"policy": a.policy_lr, "value": a.value_lr, "discriminator": a.discriminator_lr,
+            "gail_discriminator": a.gail_discriminator_lr})
+    compare(got[0], got[1], single, lrs)
+
+
+@pytest.mark.parametrize("kind", ["gail", "dgail"])
+def test_imitation_data_parallel_two_ranks_on_one_gpu(kind):
+    _imitation_world2(kind, "gloo")
+
+
+@pytest.mark.skipif(th.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+@pytest.mark.parametrize("kind", ["gail", "dgail"])
+def test_imitation_data_parallel_nccl_world2(kind):
+    _imitation_world2(kind, "nccl")
