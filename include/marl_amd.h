@@ -343,6 +343,11 @@ int ec_store_episode_static(const float* obs0, const int32_t* avail0, const floa
                             int32_t n_agents, int32_t obs_dim, int32_t n_actions, int64_t episode_limit, float* buf_obs,
                             int32_t* buf_avail, int64_t* buf_actions, float* buf_rewards, float* buf_masks,
                             float* buf_next_obs, double* totals, void* stream);
+/* Test hook of ec_store_episode_static (no counterpart in the reference either): the current device's copy of the static
+ * scratch as the library looked it up -- address and size -- after filling it with `fill_byte` on `stream` when
+ * fill_byte >= 0 (a poisoned arrival counter and stale partial sums for the next call to start from).  Allocates nothing. */
+int ec_debug_store_episode_static_scratch(int32_t fill_byte, void** ptr_out, int64_t* bytes_out, void* stream);
+
 
 /* --- fused PPO loss + gradients ----------------------------------------------------------------------------------
  * One launch per network does the forward pass, the loss and the whole backward pass of the (obs | one-hot agent id)

@@ -185,6 +185,8 @@ def lib():
     L.ec_store_transition.argtypes = [vp] * 7 + [i64, i32, i32, i32, i64, i64] + [vp] * 8
     L.ec_store_episode.argtypes = [vp] * 9 + [i64, i32, i32, i32, i64] + [vp] * 10
     L.ec_store_episode_static.argtypes = [vp] * 9 + [i64, i32, i32, i32, i64] + [vp] * 8
+    L.ec_debug_store_episode_static_scratch.argtypes = [i32, C.POINTER(vp), C.POINTER(i64), vp]
+    L.ec_debug_store_episode_static_scratch.restype = C.c_int
     for fn in ("ec_create", "ec_destroy", "ec_reset", "ec_observe", "ec_step", "ec_random_policy", "ec_status",
                "ec_debug_dump", "ec_debug_rng_cursors", "ec_debug_live_tasks", "ec_info", "ec_gae",
                "ec_policy_forward", "ec_gail_reward", "ec_diffusion_reward", "ec_diffusion_grad", "ec_expert_policy",

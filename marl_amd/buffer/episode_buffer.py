@@ -45,5 +45,24 @@ class EpisodeBuffer:
         self.next_obs_is_shifted_obs = False
         self.known_mask_sum = None
 
+    def begin_episode(self):
+        """t = 0 without zeroing the tensors (a writer that overwrites every element, ec_store_episode, follows); the
+        whole-episode flags are cleared like in reset(): whoever files the episode sets them again"""
+        self.t = 0
+        self.next_obs_is_shifted_obs = False
+        self.known_mask_sum = None
+
+    def check_whole_episode_flags(self):
+        """the claims behind next_obs_is_shifted_obs / known_mask_sum, verified on the tensors (a 147 MB comparison and a
+        device->host sync at 4096 envs: the learners run it on their first update and under args.ec_check_buffer_flags)"""
+        if self.next_obs_is_shifted_obs and self.obs.shape[1] > 1:
+            if not th.equal(self.next_obs[:, :-1], self.obs[:, 1:]):
+                raise RuntimeError("EpisodeBuffer.next_obs_is_shifted_obs is set but next_obs[:, t] != obs[:, t+1]: the buffer "
+                                   "was written to after the runner filed the episode (clear the flag, or call reset())")
+        if self.known_mask_sum is not None:
+            got = float(self.masks.sum())
+            if got != float(self.known_mask_sum):
+                raise RuntimeError("EpisodeBuffer.known_mask_sum = %r but masks.sum() = %r" % (self.known_mask_sum, got))
+
     def can_sample(self) -> bool:
         return self.t >= self.args.episode_limit

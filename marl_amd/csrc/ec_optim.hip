@@ -10,6 +10,8 @@
 //   t += 1;  m += (g - m) (1 - b1);  v = v b2 + (1 - b2) g g;
 //   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)                                  (Adam, no weight decay)
 // State (exp_avg, exp_avg_sq, step) stays in the torch optimiser's own tensors, so checkpoints do not change.
+#include <cmath>
+
 #include "ec_common.h"
 
 namespace {
@@ -25,6 +27,7 @@ struct AdamNet {
     int n[ADAM_MAX_TENSORS];
     int n_tensors;
     float step_host;
+    float step_size_host, bc2_sqrt_host;  // host step counts: lr / (1 - b1^t) and sqrt(1 - b2^t) evaluated in double, as torch does
     float lr, b1, b2, omb1, omb2, eps, max_norm;  // omb = 1 - beta rounded from double, as torch passes it; max_norm <= 0: no clipping
 };
 struct AdamArgs {
@@ -48,14 +51,18 @@ __global__ void __launch_bounds__(1024) k_adam_clip(AdamArgs args) {
         float t = 0.0f;
         for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += s_red[w];
         const float c = a.max_norm > 0.0f ? a.max_norm / (sqrtf(t) + 1e-6f) : 1.0f;
-        s_coef = c < 1.0f ? c : 1.0f;
+        s_coef = (c < 1.0f || c != c) ? c : 1.0f;  // (a NaN norm poisons every gradient, as torch's clamp lets it)
     }
     __syncthreads();
     const float coef = s_coef;
     for (int k = 0; k < a.n_tensors; k++) {
-        const float t = a.step[k] ? *a.step[k] + 1.0f : a.step_host;
-        const float bc1 = 1.0f - powf(a.b1, t), bc2 = 1.0f - powf(a.b2, t);
-        const float step_size = a.lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+        // device step counters (capturable Adam): torch evaluates the bias corrections on the fp32 step tensor too
+        float step_size = a.step_size_host, bc2_sqrt = a.bc2_sqrt_host;
+        if (a.step[k]) {
+            const float t = *a.step[k] + 1.0f;
+            step_size = a.lr / (1.0f - powf(a.b1, t));
+            bc2_sqrt = sqrtf(1.0f - powf(a.b2, t));
+        }
         for (int i = threadIdx.x; i < a.n[k]; i += blockDim.x) {
             const float g = a.g[k][i] * coef;
             float m = a.m[k][i], v = a.v[k][i];
@@ -64,7 +71,7 @@ __global__ void __launch_bounds__(1024) k_adam_clip(AdamArgs args) {
             a.g[k][i] = g;
             a.m[k][i] = m;
             a.v[k][i] = v;
-            a.p[k][i] -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + a.eps);
+            a.p[k][i] -= step_size * m / (sqrtf(v) / bc2_sqrt + a.eps);
         }
     }
     __syncthreads();  // every thread has read the step counts
@@ -104,6 +111,11 @@ extern "C" int ec_adam_clip_step(int32_t n_nets, const int32_t* n_tensors, float
         if (!dev_steps && (!step_host || !(step_host[net] >= 1.0)))
             return ec::fail(EC_EINVAL, "ec_adam_clip_step: network %d has neither device step counters nor a host step count", net);
         x.step_host = dev_steps ? 0.0f : (float)step_host[net];
+        x.step_size_host = x.bc2_sqrt_host = 1.0f;
+        if (!dev_steps) {
+            x.step_size_host = (float)(lr[net] / (1.0 - pow(beta1[net], step_host[net])));
+            x.bc2_sqrt_host = (float)sqrt(1.0 - pow(beta2[net], step_host[net]));
+        }
         x.lr = (float)lr[net];
         x.b1 = (float)beta1[net];
         x.b2 = (float)beta2[net];

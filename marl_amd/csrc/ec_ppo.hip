@@ -583,7 +583,7 @@ float* g_ws[64] = {nullptr};
 
 // the per-device workspace of the backward passes (allocated at the first one; calls on one device share it, so passes
 // that overlap on one GPU from different streams must not: MARL_AMD_PPO_ATOMICS=1 restores the atomic flush)
-int ppo_workspace(float** out) {
+int ppo_workspace(float** out, hipStream_t stream) {
     static const bool atomics = getenv("MARL_AMD_PPO_ATOMICS") && atoi(getenv("MARL_AMD_PPO_ATOMICS")) != 0;
     *out = nullptr;
     if (atomics) return EC_OK;
@@ -591,7 +591,13 @@ int ppo_workspace(float** out) {
     EC_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return EC_OK;
     std::lock_guard<std::mutex> lock(g_ws_mu);
-    if (!g_ws[dev]) EC_HIP(hipMalloc(reinterpret_cast<void**>(&g_ws[dev]), sizeof(float) * PPO_WS_STRIDE * PPO_WS_BLOCKS));
+    if (!g_ws[dev]) {
+        // a first backward pass under stream capture must not allocate (hipMalloc would break the capture): that pass
+        // flushes with atomics, and a later pass outside a capture allocates
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return EC_OK;
+        EC_HIP(hipMalloc(reinterpret_cast<void**>(&g_ws[dev]), sizeof(float) * PPO_WS_STRIDE * PPO_WS_BLOCKS));
+    }
     *out = g_ws[dev];
     return EC_OK;
 }
@@ -632,7 +638,7 @@ int launch_ppo(const PpoArgs& a, hipStream_t stream) {
         PpoArgs b = a;
         const int n3 = HEAD == 0 ? a.A : 1;
         const int n_params = H * (OBS + a.n_agents) + H + H * H + H + n3 * H + n3;
-        if (int rc = ppo_workspace(&b.ws)) return rc;
+        if (int rc = ppo_workspace(&b.ws, stream)) return rc;
         b.ws_stride = PPO_WS_STRIDE;
         if (n_params + 1 > PPO_WS_STRIDE || blocks > PPO_WS_BLOCKS) b.ws = nullptr;
         hipLaunchKernelGGL((k_ppo<HEAD, TO3, IN1T, true, NQ>), dim3((unsigned)blocks), dim3(64 * nw), lds, stream, b);

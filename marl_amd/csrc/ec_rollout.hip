@@ -274,6 +274,17 @@ extern "C" int ec_store_episode_static(const float* obs0, const int32_t* avail0,
                                 (hipStream_t)stream);
 }
 
+// test hook: the address (and size) of the current device's copy of the static scratch, optionally filled with a byte first
+// (stream-ordered): lets tests/test_zz_no_alloc.py start a call from a poisoned arrival counter and stale partial sums
+extern "C" int ec_debug_store_episode_static_scratch(int32_t fill_byte, void** ptr_out, int64_t* bytes_out, void* stream) {
+    unsigned char* base = nullptr;
+    if (int rc = scratch_of_current_device(&base)) return rc;
+    if (fill_byte >= 0) EC_HIP(hipMemsetAsync(base, fill_byte & 0xff, sizeof(scratch), (hipStream_t)stream));
+    if (ptr_out) *ptr_out = base;
+    if (bytes_out) *bytes_out = (int64_t)sizeof(scratch);
+    return EC_OK;
+}
+
 extern "C" int ec_store_transition(const float* obs, const int32_t* avail, const int64_t* actions, const float* reward,
                                    const uint8_t* terminated, const int32_t* counters, const float* completion_time,
                                    int64_t n_envs, int32_t n_agents, int32_t obs_dim, int32_t n_actions, int64_t t,

@@ -51,6 +51,7 @@ _HIP_FLAGS = (
     ("ec_graph_rollout", int, 0),  # 1: ParallelRunner replays one hipGraph per episode
     ("ec_torch_update", int, 0),   # 1: PPOAgent.train keeps the torch-autograd update instead of the fused kernels
     ("ec_kernel_rollout", int, 1),  # ParallelRunner + PPO: the whole episode (Actor + env) in one launch when the env supports it
+    ("ec_check_buffer_flags", int, 0),  # 1: verify the buffer's whole-episode flags on every PPO update (first update always)
     ("ec_graph_update", int, 1),   # DGAIL: replay one hipGraph per minibatch step of the policy/value update (single process)
     # generate_graph2 (network_graph.py:267-307): a GraphML topology instead of the synthetic ring + chords; the
     # reference reads args.topology_file with getattr and selects the loader by editing edge_node.py:38-39

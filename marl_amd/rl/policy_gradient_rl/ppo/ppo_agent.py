@@ -50,6 +50,7 @@ class PPOAgent:
         self.buffer = EpisodeBuffer(args, device=self.device)
         self._eye = th.eye(args.n_agents, device=self.device)
         self.last_losses = {}
+        self._flags_checked = False
         # fused HIP update: every p.grad is a view into one flat buffer that the kernels accumulate into
         self._fg_actor = self._fg_critic = None
         if self._fused_policy_ok() and not getattr(args, "ec_torch_update", False):
@@ -100,6 +101,12 @@ class PPOAgent:
         self._fg_critic.bind()
         obs, avail_actions, actions, rewards, masks, next_obs = self.buffer.sample()
         shape = rewards.shape
+        if not self._flags_checked or getattr(a, "ec_check_buffer_flags", False):
+            # the shortcuts below trust two claims the runner's transition store leaves on the buffer: verified on the
+            # first update (and on every one under --ec_check_buffer_flags=1)
+            self._flags_checked = True
+            if hasattr(self.buffer, "check_whole_episode_flags"):
+                self.buffer.check_whole_episode_flags()
         if a.normalize_rewards:
             mean, std = global_mean_std(rewards)
             rewards = (rewards - mean) / (std + 1e-5)

@@ -123,7 +123,7 @@ class DGAILRunner:
         B, N = args.n_threads, args.n_agents
         kernel = self._kernel_rollout_ok(test_mode)
         if kernel and not test_mode:
-            self.agent.buffer.t = 0  # ec_store_episode overwrites every element
+            self.agent.buffer.begin_episode()  # ec_store_episode overwrites every element
         else:
             self.agent.buffer.reset()
         env.reset()

@@ -122,7 +122,7 @@ class ParallelRunner:
         fast = self._store.usable(self.agent.buffer)
         kernel = fast and self._kernel_rollout_ok()
         if kernel and not test_mode:
-            self.agent.buffer.t = 0  # ec_store_episode overwrites every element: no need to zero 540 MB first
+            self.agent.buffer.begin_episode()  # ec_store_episode overwrites every element: no need to zero 540 MB first
         else:
             self.agent.buffer.reset()
         env.reset()

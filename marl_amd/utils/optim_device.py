@@ -46,19 +46,22 @@ def clip_adam_step(optimizers, max_norm):
     if not isinstance(max_norm, (list, tuple)):
         max_norm = [max_norm] * len(optimizers)
     dev = optimizers[0].param_groups[0]["params"][0].device
-    n_t, P, G, M, V, S, numel, step_host, hyper = [], [], [], [], [], [], [], [], []
+    n_t, P, G, M, V, S, numel, step_host, hyper, host_counted = [], [], [], [], [], [], [], [], [], []
+    # every optimiser is checked before any state is touched: a refusal leaves all of them as they were
+    for opt in optimizers:
+        ps = opt.param_groups[0]["params"]
+        on_dev = [("step" in opt.state[p] and opt.state[p]["step"].is_cuda) or
+                  ("step" not in opt.state[p] and opt.param_groups[0].get("capturable", False)) for p in ps]
+        if any(on_dev) != all(on_dev) or any(p.device != dev for p in ps):
+            return False
     for opt, mn in zip(optimizers, max_norm):
         g = opt.param_groups[0]
         ps = g["params"]
         n_t.append(len(ps))
         sts = [_state(opt, p) for p in ps]
-        on_dev = [st["step"].is_cuda for st in sts]
-        if any(on_dev) != all(on_dev) or any(p.device != dev for p in ps):
-            return False
-        if not all(on_dev):  # the host keeps the count (non-capturable Adam): advance it here
-            for st in sts:
-                st["step"] += 1
-            step_host.append(float(sts[0]["step"]))
+        if not sts[0]["step"].is_cuda:  # the host keeps the count (non-capturable Adam): advanced once the launch is made
+            step_host.append(float(sts[0]["step"]) + 1.0)
+            host_counted.append(sts)
         else:
             step_host.append(0.0)
         for p, st in zip(ps, sts):
@@ -79,6 +82,9 @@ def clip_adam_step(optimizers, max_norm):
             f32s(step_host), f32s([h[0] for h in hyper]), f32s([h[1] for h in hyper]), f32s([h[2] for h in hyper]),
             f32s([h[3] for h in hyper]), f32s([h[4] for h in hyper]),
             C.c_void_p(th.cuda.current_stream(dev).cuda_stream)), "ec_adam_clip_step")
+    for sts in host_counted:  # (after the launch's return code: a failed call has advanced nothing)
+        for st in sts:
+            st["step"] += 1
     for opt in optimizers:
         opt._opt_called = True  # (what an lr_scheduler looks at to tell that step() came first)
     return True

@@ -74,6 +74,40 @@ def test_static_scratch_matches_workspace_variant_twice():
             assert th.equal(tot_s[2:], want_counts)
 
 
+def test_static_entry_point_allocates_no_device_memory_and_survives_a_poisoned_scratch():
+    """The property the entry point exists for: a call leaves the device's free memory where it was (no hipMalloc behind
+    it; the inputs and outputs are made beforehand and nothing goes through torch's allocator in between).  And the
+    hipMemsetAsync that guards the arrival counter: a scratch filled with 0xFF -- counter 0xFFFFFFFF, partial sums NaN --
+    gives the same buffers and totals as the workspace variant."""
+    from marl_amd import _abi
+    dev = th.device("cuda:0")
+    L = _abi.lib()
+    N, O, B, T = 10, 9, 64, 50
+    A = N + 1
+    h = _episode(B, T, N, O, A, seed=21, dev=dev)
+    tot_s = th.zeros(6, dtype=th.float64, device=dev)
+    tot_w = th.zeros(6, dtype=th.float64, device=dev)
+    want = _run(False, h, B, T, N, O, A, tot_w, dev)
+    _run(True, h, B, T, N, O, A, tot_s, dev)                        # warm call: the symbol's address is looked up here
+    bufs = _buffers(B, T, N, O, A, dev)
+    stream = C.c_void_p(th.cuda.current_stream(dev).cuda_stream)
+    head = [_p(h["obs0"]), _p(h["avail0"]), _p(h["obs"]), _p(h["avail"]), _p(h["actions"]), _p(h["reward"]),
+            _p(h["term"]), _p(h["counters"]), _p(h["ctime"]), B, N, O, A, T] + [_p(b) for b in bufs] + [_p(tot_s)]
+    tot_s.zero_()
+    ptr, nbytes = C.c_void_p(), C.c_int64()
+    _abi.check(L.ec_debug_store_episode_static_scratch(0xFF, C.byref(ptr), C.byref(nbytes), stream), "scratch hook")
+    assert ptr.value and nbytes.value == 256 + 4096 * 48
+    th.cuda.synchronize(dev)
+    free0 = th.cuda.mem_get_info(dev)[0]
+    _abi.check(L.ec_store_episode_static(*head, stream), "ec_store_episode_static")
+    th.cuda.synchronize(dev)
+    free1 = th.cuda.mem_get_info(dev)[0]
+    assert free1 == free0, (free0, free1)
+    for i, (g, w) in enumerate(zip(bufs, want)):
+        assert th.equal(g, w), i
+    assert th.equal(tot_s, tot_w) and bool(th.isfinite(tot_s).all())
+
+
 def test_static_scratch_statistics_only_and_limit():
     from marl_amd import _abi
     dev = th.device("cuda:0")
