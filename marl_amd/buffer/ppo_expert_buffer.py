@@ -8,3 +8,5 @@ class PPOExpertBuffer(EpisodeBuffer):
         for dst, src in ((self.obs, obs), (self.avail_actions, avail_actions), (self.actions, actions),
                          (self.rewards, rewards), (self.masks, masks), (self.next_obs, next_obs)):
             dst.copy_(src)
+        self.next_obs_is_shifted_obs = False  # (written in place: the whole-episode claims no longer hold)
+        self.known_mask_sum = None

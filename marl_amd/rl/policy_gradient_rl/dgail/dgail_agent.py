@@ -83,6 +83,7 @@ class DGAILAgent:
         self.min_bc_weight = getattr(args, "min_bc_weight", 0.05)
         self.performance_history = []
         self._eye = th.eye(self.n_agents, device=self.device)
+        self._flags_checked = False
         # fused HIP minibatch update of policy / value (ec_ppo_*_grad_ex): every p.grad is a view into one flat buffer
         # per network that the kernels accumulate into, the BC term's autograd adds to, and the DP all-reduce reduces
         self._fg_policy = self._fg_value = self._fg_gail = self._fg_bc = None
@@ -384,9 +385,10 @@ class DGAILAgent:
         self._fg_value.bind()
         obs_f = obs.reshape(-1, self.obs_shape)
         act_f = actions.reshape(-1)
-        values = ppo_device.critic_pass(self.value, obs_f, None, 0, want_values=True).view(B, T, N, 1)
-        next_values = ppo_device.critic_pass(self.value, next_obs.reshape(-1, self.obs_shape), None, 0,
-                                             want_values=True).view(B, T, N, 1)
+        if not self._flags_checked or getattr(a, "ec_check_buffer_flags", False):
+            self._flags_checked = True
+            self.buffer.check_whole_episode_flags()
+        values, next_values = ppo_device.values_and_next_values(self.value, obs, next_obs, None, 0, self.buffer)
         advantages = get_gae(a, rewards, values, next_values, masks)
         ret_f = (advantages + values).reshape(-1)
         mean, std = global_mean_std(advantages)

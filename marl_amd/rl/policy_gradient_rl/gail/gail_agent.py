@@ -53,6 +53,7 @@ class GAILAgent:
         self.performance_history = []
         self._eye = th.eye(args.n_agents, device=self.device)
         self.last_losses = {}
+        self._flags_checked = False
         # fused HIP update of actor / critic (see PPOAgent): p.grad views one flat buffer per network
         self._fg_actor = self._fg_critic = None
         if self._fused_ok() and not getattr(args, "ec_torch_update", False):
@@ -163,18 +164,24 @@ class GAILAgent:
         self._fg_actor.bind()
         self._fg_critic.bind()
         shape = rewards.shape
+        if not self._flags_checked or getattr(a, "ec_check_buffer_flags", False):
+            self._flags_checked = True  # (the two claims of the runner's transition store behind the shortcuts below)
+            self.buffer.check_whole_episode_flags()
         if a.normalize_rewards:
             mean, std = global_mean_std(rewards)
             rewards = (rewards - mean) / (std + 1e-8)
         old_logp = None  # (left by the actor's pass of epoch 0, whose parameters are still the rollout's: EC_PPO_FIRST_EPOCH)
-        old_v = ppo_device.critic_pass(self.critic, obs, masks, N, want_values=True).view(shape)
-        old_next_v = ppo_device.critic_pass(self.critic, next_obs, masks, N, want_values=True).view(shape)
+        old_v, old_next_v = ppo_device.values_and_next_values(self.critic, obs, next_obs, masks, N, self.buffer)
         advantages = get_gae(a, rewards, old_v, old_next_v, masks)
         if a.normalize_advantages:
             mean, std = global_mean_std(advantages)
             advantages = (advantages - mean) / (std + 1e-8)
         targets = advantages + old_v
-        inv_denom = 1.0 / float(all_reduce_sum_(masks.sum().reshape(1).clone()))
+        known = getattr(self.buffer, "known_mask_sum", None)
+        if known is not None and world_size() == 1:
+            inv_denom = 1.0 / known  # the runner filed a whole episode: no device->host sync for masks.sum()
+        else:
+            inv_denom = 1.0 / float(all_reduce_sum_(masks.sum().reshape(1).clone()))
         self.update_bc_weight()
         losses = th.zeros(2, device=self.device)
         n_expert = len(self.expert_transitions)

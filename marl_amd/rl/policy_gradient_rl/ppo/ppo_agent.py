@@ -113,16 +113,7 @@ class PPOAgent:
         # (old log-probs, ppo_agent.py:96: left by the actor's pass of epoch 0, whose parameters are still the rollout's --
         # no forward-only launch for them)
         old_logp = None
-        old_v = ppo_device.critic_pass(self.critic, obs, masks, N, want_values=True).view(shape)
-        if shape[1] > 1 and getattr(self.buffer, "next_obs_is_shifted_obs", False):
-            # the runner's transition store filed one observation as next_obs[t] and obs[t+1] (it says so on the
-            # buffer): V(next_obs[t]) is V(obs[t+1]) (the kernel evaluates rows independently, so the values are the
-            # same bits); only the last step needs a pass
-            last = ppo_device.critic_pass(self.critic, next_obs[:, -1:].contiguous(), masks[:, -1:].contiguous(), N,
-                                          want_values=True).view(shape[0], 1, *shape[2:])
-            old_next_v = th.cat([old_v[:, 1:], last], dim=1)
-        else:
-            old_next_v = ppo_device.critic_pass(self.critic, next_obs, masks, N, want_values=True).view(shape)
+        old_v, old_next_v = ppo_device.values_and_next_values(self.critic, obs, next_obs, masks, N, self.buffer)
         advantages = get_gae(a, rewards, old_v, old_next_v, masks)
         if a.normalize_advantages:
             mean, std = global_mean_std(advantages)

@@ -144,3 +144,19 @@ def gail_disc_pass(disc, obs, actions, expert, inv_denom=1.0, grads=None, loss=N
                                                 C.c_float(inv_denom), _p(grads), _p(loss), _p(prob), _stream(dev)),
                    "ec_gail_disc_grad")
     return prob
+
+
+def values_and_next_values(critic, obs, next_obs, masks, n_agents, buffer=None):
+    """V(obs) and V(next_obs), both shaped like obs[..., :1] ([B, T, N, 1]; ppo_agent.py:98-100, gail_agent.py:186-188,
+    dgail_agent.py:258-262).  When the runner's transition store filed one observation as next_obs[:, t] and obs[:, t+1]
+    (it says so on the buffer: EpisodeBuffer.next_obs_is_shifted_obs), V(next_obs[:, t]) IS V(obs[:, t+1]) -- the kernel
+    evaluates rows independently, so the values are the same bits -- and only the last step needs a pass of its own."""
+    shape = tuple(obs.shape[:-1]) + (1,)
+    v = critic_pass(critic, obs, masks, n_agents, want_values=True).view(shape)
+    if shape[1] > 1 and buffer is not None and getattr(buffer, "next_obs_is_shifted_obs", False):
+        last_mask = masks[:, -1:].contiguous() if masks is not None else None
+        last = critic_pass(critic, next_obs[:, -1:].contiguous(), last_mask, n_agents, want_values=True)
+        nv = th.cat([v[:, 1:], last.view(shape[0], 1, *shape[2:])], dim=1)
+    else:
+        nv = critic_pass(critic, next_obs, masks, n_agents, want_values=True).view(shape)
+    return v, nv

@@ -24,3 +24,10 @@ L.ec_debug_stamps(env._h, buf.ctypes.data_as(C.c_void_p), C.byref(n))
 buf = buf[: n.value].astype(np.float64) / 100.0 / T  # wall_clock64 ticks at 100 MHz -> us per step
 for name, i in (("policy tile (wave 0)", 9), ("wait others + action", 10), ("step body", 11), ("loop gap", 12)):
     print("%-24s mean %.2f us  p10 %.2f  p90 %.2f" % (name, buf[:, i].mean(), np.percentile(buf[:, i], 10), np.percentile(buf[:, i], 90)))
+# phases of the LAST step body of the launch (EC_STAMP points 0..8 of step_body; 9..12 were overwritten by the totals above)
+raw = np.zeros((B, 16), dtype=np.uint64)
+L.ec_debug_stamps(env._h, raw.ctypes.data_as(C.c_void_p), C.byref(n))
+s = raw[: n.value].astype(np.int64)
+names = ["entry->staged", "offload", "fail window", "mini-slots", "reduce", "generate+writeback", "(unused)", "observe"]
+for i, nm in enumerate(names):
+    print("  %-24s mean %6.2f us" % (nm, (s[:, i + 1] - s[:, i]).mean() / 100.0))
