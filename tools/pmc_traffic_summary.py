@@ -9,14 +9,16 @@ import re
 import sys
 
 out_dir, mode = sys.argv[1], sys.argv[2]
-want = {"rollout": "k_step<4, 4, true>", "step": "k_step<4, 4, false>", "mlp": "k_rollout_mlp<4, 4, false, 1>"}[mode]
+# (name prefixes: the instantiations of the default geometry carry the block's lane count as a last template argument)
+want = {"rollout": "k_step<4, 4, true", "step": "k_step<4, 4, false", "mlp": "k_rollout_mlp<4, 4, false, 1"}[mode]
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = []
     for f in glob.glob(os.path.join(out_dir, "%s_%s" % (mode, c), "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             m = re.search(r"\b(k_\w+(<[^>]*>)?)", r["Kernel_Name"])
-            if m and m.group(1) == want and r["Counter_Name"] == c:
+            if m and m.group(1).startswith(want) and r["Counter_Name"] == c:
+                kernel_name = m.group(1)
                 acc.append(float(r["Counter_Value"]))
     if mode != "step":
         acc = acc[1:] if len(acc) > 1 else acc  # the first launch also pages the state in
@@ -24,7 +26,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 fetch_raw = vals["FETCH_SIZE"][0] * 1024.0
 write = vals["WRITE_SIZE"][0] * 1024.0
 steps = 1 if mode == "step" else 100
-rec = {"kernel": want, "workload": "tools/prof_step.py (4096 envs x 10 agents), mode %s, %d env steps per launch" % (mode, steps),
+rec = {"kernel": kernel_name, "workload": "tools/prof_step.py (4096 envs x 10 agents), mode %s, %d env steps per launch" % (mode, steps),
        "FETCH_SIZE_KB_avg": vals["FETCH_SIZE"][0], "WRITE_SIZE_KB_avg": vals["WRITE_SIZE"][0],
        "launches": vals["FETCH_SIZE"][1], "env_steps_per_launch": steps,
        "fetch_bytes_raw": fetch_raw, "write_bytes": write, "fetch_bytes_corrected": 2 * fetch_raw,
