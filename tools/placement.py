@@ -26,7 +26,7 @@ env.observe()
 env.random_actions(seed=0, counter=0, out=act)
 env.rollout_random_policy(act, 60, seed=0)
 nb = B // env.info_geometry()["envs_per_block"] + 1
-buf = np.zeros((nb + 8) * 16, dtype=np.uint64)
+buf = np.zeros((nb + 8) * 32, dtype=np.uint64)  # (the library copies 32 words per block)
 n = C.c_int64()
 L.ec_debug_stamps(env._h, buf.ctypes.data_as(C.c_void_p), C.byref(n))
 s = buf[: n.value * 16].reshape(n.value, 16)
