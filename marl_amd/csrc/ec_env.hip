@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "ec_common.h"
@@ -178,66 +179,144 @@ struct alignas(16) EcDev {
     u64* stamps;    // [blocks][16] phase time stamps (EC_STAMPS diagnostic build only), else null
 };
 
-// A pointer that reaches a kernel inside a struct read from memory is generic to the compiler (flat loads and
-// stores); one that arrives as a kernel argument is known to be global.  The looping kernel reads its EcDev from
-// memory, so it passes every pointer member through the global address space (plus an offset of zero that the
-// compiler cannot see through) on its way back to a generic pointer: provenance the address-space inference uses.
-template <typename T>
-__device__ __forceinline__ T* as_global(T* p, size_t zero) {
-    typedef T __attribute__((address_space(1))) GT;
-    return (T*)((GT*)p + zero);  // the (opaque) offset keeps the two casts from cancelling
-}
-__device__ __forceinline__ void ec_dev_globalize(EcDev& d, size_t zero) {
-#define EC_G(f) d.f = as_global(d.f, zero)
-    EC_G(acc);
-    EC_G(cap);
-    EC_G(thr_exec_m);
-    EC_G(hot_thr);
-    EC_G(qlen);
-    EC_G(qthr);
-    EC_G(obs_const);
-    EC_G(bin_qn);
-    EC_G(bin_px2);
-    EC_G(bin_flip);
-    EC_G(deg);
-    EC_G(in_src);
-    EC_G(thr_link_m);
-    EC_G(slot_of);
-    EC_G(rate);
-    EC_G(adj);
-    EC_G(adj_bits);
-    EC_G(efr);
-    EC_G(tfr);
-    EC_G(cores);
-    EC_G(mt);
-    EC_G(rng_pos);
-    EC_G(rng_ahead);
-    EC_G(rng_cnt);
-    EC_G(has_new);
-    EC_G(newt);
-    EC_G(buf_head);
-    EC_G(buf_len);
-    EC_G(buf);
-    EC_G(wq_len);
-    EC_G(wqm);
-    EC_G(wqe);
-    EC_G(ex_n);
-    EC_G(exA);
-    EC_G(exB);
-    EC_G(exC);
-    EC_G(rq_head);
-    EC_G(rq_len);
-    EC_G(rq_arrive);
-    EC_G(rq_hstart);
-    EC_G(rq);
-    EC_G(n_off);
-    EC_G(cur_step);
-    EC_G(tick);
-    EC_G(total_steps);
-    EC_G(hop_hist);
-    EC_G(status);
-    EC_G(stamps);
-#undef EC_G
+// The looping kernels' view of the geometry block.  A step needs a few dozen of its ~150 words and the launch's first and
+// last steps most of the rest; read into scalar registers as a whole at the top of every step (the only way to keep the
+// compiler from holding all of it live across the loop) it cost 38 LDS reads, 152 v_readfirstlane, ~130 spill writes and
+// 110 scalar adds per step: 1.8 of a step's 18.8 us, by the stamps.  Here the block sits in the lanes of DEV_VREGS vector
+// registers for the whole launch (lane i of register j = word 64 j + i, three loads per wave and launch) and a member is
+// read where it is used: one v_readlane per word -- what a scalar spill reload costs, without the spill.  Members
+// convert implicitly, so `d.N`, `d.cap[node]`, `d.rq + i` read as they do on the plain struct; pointers come out as
+// global-address-space pointers (built from the integer, so there is no generic -> global cast to fold away).
+constexpr int DEV_WORDS = (int)(sizeof(EcDev) / 4);
+constexpr int DEV_VREGS = (DEV_WORDS + 63) / 64;
+template <typename T, size_t OFF>
+struct DevField {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "geometry members are one or two words");
+    static_assert(OFF % 4 == 0, "word-aligned member");
+    const u32 (&v)[DEV_VREGS];
+    __device__ __forceinline__ operator T() const {
+        constexpr int w = (int)(OFF / 4);
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)v[w / 64], w % 64);
+        if constexpr (sizeof(T) == 4) {
+            T r;
+            __builtin_memcpy(&r, &lo, 4);
+            return r;
+        } else {
+            const u32 hi = (u32)__builtin_amdgcn_readlane((int)v[(w + 1) / 64], (w + 1) % 64);
+            const u64 x = (u64)lo | ((u64)hi << 32);
+            if constexpr (std::is_pointer<T>::value) {
+                typedef typename std::remove_pointer<T>::type E;
+                typedef E __attribute__((address_space(1))) GE;
+                return (T) reinterpret_cast<GE*>(x);
+            } else {
+                T r;
+                __builtin_memcpy(&r, &x, 8);
+                return r;
+            }
+        }
+    }
+};
+struct EcDevL {
+    DevField<decltype(EcDev::N), offsetof(EcDev, N)> N;
+    DevField<decltype(EcDev::A), offsetof(EcDev, A)> A;
+    DevField<decltype(EcDev::k), offsetof(EcDev, k)> k;
+    DevField<decltype(EcDev::D), offsetof(EcDev, D)> D;
+    DevField<decltype(EcDev::S), offsetof(EcDev, S)> S;
+    DevField<decltype(EcDev::T), offsetof(EcDev, T)> T;
+    DevField<decltype(EcDev::H), offsetof(EcDev, H)> H;
+    DevField<decltype(EcDev::capB), offsetof(EcDev, capB)> capB;
+    DevField<decltype(EcDev::capR), offsetof(EcDev, capR)> capR;
+    DevField<decltype(EcDev::capW), offsetof(EcDev, capW)> capW;
+    DevField<decltype(EcDev::maxTicks), offsetof(EcDev, maxTicks)> maxTicks;
+    DevField<decltype(EcDev::epb), offsetof(EcDev, epb)> epb;
+    DevField<decltype(EcDev::epw), offsetof(EcDev, epw)> epw;
+    DevField<decltype(EcDev::nmain), offsetof(EcDev, nmain)> nmain;
+    DevField<decltype(EcDev::dl_ticks), offsetof(EcDev, dl_ticks)> dl_ticks;
+    DevField<decltype(EcDev::divN), offsetof(EcDev, divN)> divN;
+    DevField<decltype(EcDev::divA), offsetof(EcDev, divA)> divA;
+    DevField<decltype(EcDev::fast_dl), offsetof(EcDev, fast_dl)> fast_dl;
+    DevField<decltype(EcDev::acc_words), offsetof(EcDev, acc_words)> acc_words;
+    DevField<decltype(EcDev::B), offsetof(EcDev, B)> B;
+    DevField<decltype(EcDev::P), offsetof(EcDev, P)> P;
+    DevField<decltype(EcDev::dt), offsetof(EcDev, dt)> dt;
+    DevField<decltype(EcDev::inv_dt), offsetof(EcDev, inv_dt)> inv_dt;
+    DevField<decltype(EcDev::deadline), offsetof(EcDev, deadline)> deadline;
+    DevField<decltype(EcDev::size_lo), offsetof(EcDev, size_lo)> size_lo;
+    DevField<decltype(EcDev::size_range), offsetof(EcDev, size_range)> size_range;
+    DevField<decltype(EcDev::cx_lo), offsetof(EcDev, cx_lo)> cx_lo;
+    DevField<decltype(EcDev::cx_range), offsetof(EcDev, cx_range)> cx_range;
+    DevField<decltype(EcDev::pen_drop), offsetof(EcDev, pen_drop)> pen_drop;
+    DevField<decltype(EcDev::pen_fail), offsetof(EcDev, pen_fail)> pen_fail;
+    DevField<decltype(EcDev::rew_succ), offsetof(EcDev, rew_succ)> rew_succ;
+    DevField<decltype(EcDev::pen_hop), offsetof(EcDev, pen_hop)> pen_hop;
+    DevField<decltype(EcDev::obs_size_norm), offsetof(EcDev, obs_size_norm)> obs_size_norm;
+    DevField<decltype(EcDev::obs_cyc_norm), offsetof(EcDev, obs_cyc_norm)> obs_cyc_norm;
+    DevField<decltype(EcDev::acc), offsetof(EcDev, acc)> acc;
+    DevField<decltype(EcDev::cap), offsetof(EcDev, cap)> cap;
+    DevField<decltype(EcDev::thr_exec_m), offsetof(EcDev, thr_exec_m)> thr_exec_m;
+    DevField<decltype(EcDev::hot_thr), offsetof(EcDev, hot_thr)> hot_thr;
+    DevField<decltype(EcDev::qlen), offsetof(EcDev, qlen)> qlen;
+    DevField<decltype(EcDev::qthr), offsetof(EcDev, qthr)> qthr;
+    DevField<decltype(EcDev::obs_const), offsetof(EcDev, obs_const)> obs_const;
+    DevField<decltype(EcDev::bin_qn), offsetof(EcDev, bin_qn)> bin_qn;
+    DevField<decltype(EcDev::bin_px2), offsetof(EcDev, bin_px2)> bin_px2;
+    DevField<decltype(EcDev::bin_flip), offsetof(EcDev, bin_flip)> bin_flip;
+    DevField<decltype(EcDev::deg), offsetof(EcDev, deg)> deg;
+    DevField<decltype(EcDev::in_src), offsetof(EcDev, in_src)> in_src;
+    DevField<decltype(EcDev::thr_link_m), offsetof(EcDev, thr_link_m)> thr_link_m;
+    DevField<decltype(EcDev::slot_of), offsetof(EcDev, slot_of)> slot_of;
+    DevField<decltype(EcDev::rate), offsetof(EcDev, rate)> rate;
+    DevField<decltype(EcDev::adj), offsetof(EcDev, adj)> adj;
+    DevField<decltype(EcDev::adj_bits), offsetof(EcDev, adj_bits)> adj_bits;
+    DevField<decltype(EcDev::efr), offsetof(EcDev, efr)> efr;
+    DevField<decltype(EcDev::tfr), offsetof(EcDev, tfr)> tfr;
+    DevField<decltype(EcDev::cores), offsetof(EcDev, cores)> cores;
+    DevField<decltype(EcDev::mt), offsetof(EcDev, mt)> mt;
+    DevField<decltype(EcDev::rng_pos), offsetof(EcDev, rng_pos)> rng_pos;
+    DevField<decltype(EcDev::rng_ahead), offsetof(EcDev, rng_ahead)> rng_ahead;
+    DevField<decltype(EcDev::rng_cnt), offsetof(EcDev, rng_cnt)> rng_cnt;
+    DevField<decltype(EcDev::has_new), offsetof(EcDev, has_new)> has_new;
+    DevField<decltype(EcDev::newt), offsetof(EcDev, newt)> newt;
+    DevField<decltype(EcDev::buf_head), offsetof(EcDev, buf_head)> buf_head;
+    DevField<decltype(EcDev::buf_len), offsetof(EcDev, buf_len)> buf_len;
+    DevField<decltype(EcDev::buf), offsetof(EcDev, buf)> buf;
+    DevField<decltype(EcDev::wq_len), offsetof(EcDev, wq_len)> wq_len;
+    DevField<decltype(EcDev::wqm), offsetof(EcDev, wqm)> wqm;
+    DevField<decltype(EcDev::wqe), offsetof(EcDev, wqe)> wqe;
+    DevField<decltype(EcDev::ex_n), offsetof(EcDev, ex_n)> ex_n;
+    DevField<decltype(EcDev::exA), offsetof(EcDev, exA)> exA;
+    DevField<decltype(EcDev::exB), offsetof(EcDev, exB)> exB;
+    DevField<decltype(EcDev::exC), offsetof(EcDev, exC)> exC;
+    DevField<decltype(EcDev::rq_head), offsetof(EcDev, rq_head)> rq_head;
+    DevField<decltype(EcDev::rq_len), offsetof(EcDev, rq_len)> rq_len;
+    DevField<decltype(EcDev::rq_arrive), offsetof(EcDev, rq_arrive)> rq_arrive;
+    DevField<decltype(EcDev::rq_hstart), offsetof(EcDev, rq_hstart)> rq_hstart;
+    DevField<decltype(EcDev::rq), offsetof(EcDev, rq)> rq;
+    DevField<decltype(EcDev::n_off), offsetof(EcDev, n_off)> n_off;
+    DevField<decltype(EcDev::cur_step), offsetof(EcDev, cur_step)> cur_step;
+    DevField<decltype(EcDev::tick), offsetof(EcDev, tick)> tick;
+    DevField<decltype(EcDev::total_steps), offsetof(EcDev, total_steps)> total_steps;
+    DevField<decltype(EcDev::hop_hist), offsetof(EcDev, hop_hist)> hop_hist;
+    DevField<decltype(EcDev::status), offsetof(EcDev, status)> status;
+    DevField<decltype(EcDev::stamps), offsetof(EcDev, stamps)> stamps;
+    __device__ __forceinline__ explicit EcDevL(const u32 (&v_)[DEV_VREGS])
+        : N{v_}, A{v_}, k{v_}, D{v_}, S{v_}, T{v_}, H{v_}, capB{v_},
+          capR{v_}, capW{v_}, maxTicks{v_}, epb{v_}, epw{v_}, nmain{v_}, dl_ticks{v_}, divN{v_},
+          divA{v_}, fast_dl{v_}, acc_words{v_}, B{v_}, P{v_}, dt{v_}, inv_dt{v_}, deadline{v_},
+          size_lo{v_}, size_range{v_}, cx_lo{v_}, cx_range{v_}, pen_drop{v_}, pen_fail{v_}, rew_succ{v_}, pen_hop{v_},
+          obs_size_norm{v_}, obs_cyc_norm{v_}, acc{v_}, cap{v_}, thr_exec_m{v_}, hot_thr{v_}, qlen{v_}, qthr{v_},
+          obs_const{v_}, bin_qn{v_}, bin_px2{v_}, bin_flip{v_}, deg{v_}, in_src{v_}, thr_link_m{v_}, slot_of{v_},
+          rate{v_}, adj{v_}, adj_bits{v_}, efr{v_}, tfr{v_}, cores{v_}, mt{v_}, rng_pos{v_},
+          rng_ahead{v_}, rng_cnt{v_}, has_new{v_}, newt{v_}, buf_head{v_}, buf_len{v_}, buf{v_}, wq_len{v_},
+          wqm{v_}, wqe{v_}, ex_n{v_}, exA{v_}, exB{v_}, exC{v_}, rq_head{v_}, rq_len{v_},
+          rq_arrive{v_}, rq_hstart{v_}, rq{v_}, n_off{v_}, cur_step{v_}, tick{v_}, total_steps{v_}, hop_hist{v_},
+          status{v_}, stamps{v_} {}
+};
+// lane image of *mem for this wave (every wave of the block holds its own)
+__device__ __forceinline__ void dev_lanes_load(u32 (&v)[DEV_VREGS], const EcDev* mem) {
+    const int l = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < DEV_VREGS; j++) v[j] = 64 * j + l < DEV_WORDS ? reinterpret_cast<const u32*>(mem)[64 * j + l] : 0u;
 }
 
 // ------------------------------------------------------------------------------------------ helpers
@@ -245,7 +324,8 @@ __device__ __forceinline__ double dadd(double a, double b) { return __dadd_rn(a,
 __device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a, b); }
 __device__ __forceinline__ double ddiv(double a, double b) { return __ddiv_rn(a, b); }
 
-__device__ __forceinline__ void flag(const EcDev& d, u32 bit) { atomicOr(d.status, bit); }
+template <class DEV>
+__device__ __forceinline__ void flag(const DEV& d, u32 bit) { atomicOr(d.status, bit); }
 
 // tick LUT.  A reference timer is dt added n times in fp64 (edge_node.py:216,250,254,316,319), which is not n * dt:
 // the roundings accumulate.  The LUT stores, per n, the (small) distance in units in the last place between the two:
@@ -255,22 +335,31 @@ __device__ __forceinline__ void flag(const EcDev& d, u32 bit) { atomicOr(d.statu
 // instructions of the mini-slot loop).  An index beyond the LUT is clamped and remembered in `ovf` (reported through
 // the status word by the caller).
 typedef const int16_t __attribute__((address_space(3))) * lds_ci16_ptr;
+// (maxTicks is copied in: of the geometry members the lookups use it is the one that pays for a register of its own
+// inside the mini-slot loop; dt and the rest are read where they are used, see EcDevL)
+template <class DEV>
 struct Lut {
-    const EcDev& d;
+    const DEV& d;
+    u32 maxTicks;
+#define dt ((double)d.dt)
+#define inv_dt ((double)d.inv_dt)
+#define deadline ((double)d.deadline)
+#define dl_ticks ((int)d.dl_ticks)
+#define fast_dl ((int)d.fast_dl)
     lds_ci16_ptr s_acc;  // explicitly LDS
     mutable u32 ovf;
     __device__ __forceinline__ double make(u32 n, int corr) const {
-        return __longlong_as_double(__double_as_longlong(dmul((double)n, d.dt)) + (long long)corr);
+        return __longlong_as_double(__double_as_longlong(dmul((double)n, dt)) + (long long)corr);
     }
     __device__ __forceinline__ double at(u32 n) const {
-        ovf |= n > (u32)d.maxTicks ? 1u : 0u;
-        n = n > (u32)d.maxTicks ? (u32)d.maxTicks : n;
+        ovf |= n > maxTicks ? 1u : 0u;
+        n = n > maxTicks ? maxTicks : n;
         return make(n, s_acc[n]);  // (the whole table is in LDS: d.acc_words)
     }
     // acc[n .. n+3] (indices clamped to the LUT) with the four loads in flight together: the searches below
     // advance four candidates per round trip instead of one
     __device__ __forceinline__ void peek4(u32 n, double (&a)[4]) const {
-        const u32 mx = (u32)d.maxTicks;
+        const u32 mx = maxTicks;
         u32 i[4];
         int c[4];
 #pragma unroll
@@ -284,17 +373,17 @@ struct Lut {
     __device__ __forceinline__ u32 ticks_to_reach(double x) const {
         // starting point only.  acc[n] is n * dt up to accumulated rounding, so the answer is floor(est) or
         // floor(est) + 1 and any start at or below it gives the same result (acc is non-decreasing)
-        const double est = x * d.inv_dt;
+        const double est = x * inv_dt;
         u32 n = 0;
-        if (est > 2.0) n = est >= (double)d.maxTicks ? (u32)d.maxTicks : (u32)est - 2u;
-        while (n <= (u32)d.maxTicks) {
+        if (est > 2.0) n = est >= (double)maxTicks ? maxTicks : (u32)est - 2u;
+        while (n <= maxTicks) {
             double a[4];
             peek4(n, a);  // acc is non-decreasing: the first candidate to reach x is the count of those below it
             const u32 below = (a[0] < x ? 1u : 0u) + (a[1] < x ? 1u : 0u) + (a[2] < x ? 1u : 0u) + (a[3] < x ? 1u : 0u);
             n += below;
             if (below < 4u) break;
         }
-        return n > (u32)d.maxTicks ? T16_NEVER : n;
+        return n > maxTicks ? T16_NEVER : n;
     }
     // The reference's task_time (edge_node.py:255,301): ((((ewt + cet) + twt) + ctt) + bwt) in fp64.
     __device__ __forceinline__ double task_time(u32 ewt, u32 cet, u32 twt, u32 ctt, u32 bwt) const {
@@ -303,15 +392,15 @@ struct Lut {
     // smallest n >= 1 such that task_time with the free timer at n ticks exceeds the deadline, and that
     // task_time.  which = 0: free timer is ewt (cet = 0);  which = 1: free timer is cet (ewt fixed).
     //
-    // Closed form (d.fast_dl): every timer is its tick count times dt up to rounding, so a task_time of K ticks in all
+    // Closed form (fast_dl): every timer is its tick count times dt up to rounding, so a task_time of K ticks in all
     // is K * dt up to a bound E the host has evaluated for this LUT (build()): it cannot exceed the deadline for
     // K <= dl_ticks - 1 and must exceed it for K >= dl_ticks + 2, whatever the split over the five timers.  Only the
     // free-timer values with K = dl_ticks or dl_ticks + 1 need the fp64 sum: no search loop.
     __device__ __forceinline__ u32 deadline_ticks(int which, u32 ewt, u32 twt, u32 ctt, u32 bwt, double* tt_out) const {
         const u32 others = twt + ctt + bwt + (which ? ewt : 0u);
         const double tail0 = at(twt), tail1 = at(ctt), tail2 = at(bwt), fixed = which ? at(ewt) : 0.0;
-        if (d.fast_dl) {
-            const int nlo = d.dl_ticks - (int)others;
+        if (fast_dl) {
+            const int nlo = dl_ticks - (int)others;
             const u32 c0 = nlo < 1 ? 1u : (u32)nlo;  // (c0 + 2 <= dl_ticks + 2 <= maxTicks: checked by the host)
             double tt[3];
 #pragma unroll
@@ -320,13 +409,13 @@ struct Lut {
                 const double head = which ? dadd(fixed, a) : dadd(a, 0.0);
                 tt[j] = dadd(dadd(dadd(head, tail0), tail1), tail2);
             }
-            const bool h0 = tt[0] > d.deadline, h1 = tt[1] > d.deadline;
+            const bool h0 = tt[0] > deadline, h1 = tt[1] > deadline;
             *tt_out = h0 ? tt[0] : (h1 ? tt[1] : tt[2]);
             return h0 ? c0 : (h1 ? c0 + 1 : c0 + 2);
         }
-        const int nominal = d.dl_ticks - (int)others - 1;
+        const int nominal = dl_ticks - (int)others - 1;
         u32 n = nominal < 1 ? 1u : (u32)nominal;
-        while (n <= (u32)d.maxTicks) {
+        while (n <= maxTicks) {
             double a[4], tt[4];
             peek4(n, a);
 #pragma unroll
@@ -336,7 +425,7 @@ struct Lut {
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (n + j <= (u32)d.maxTicks && tt[j] > d.deadline) {
+                if (n + j <= maxTicks && tt[j] > deadline) {
                     *tt_out = tt[j];
                     return n + j;
                 }
@@ -347,6 +436,15 @@ struct Lut {
         return T16_NEVER;
     }
 };
+#undef dt
+#undef inv_dt
+#undef deadline
+#undef dl_ticks
+#undef fast_dl
+template <class DEV>
+__device__ __forceinline__ Lut<DEV> make_lut(const DEV& d, lds_ci16_ptr s_acc) {
+    return Lut<DEV>{d, (u32)d.maxTicks, s_acc, 0u};
+}
 
 template <typename R>
 __device__ __forceinline__ R load_rec(const R* p) {
@@ -652,7 +750,8 @@ __device__ __forceinline__ u32 fdiv(u32 n, FastDiv dv) { return dv.d == 1 ? n : 
 struct Buffer {
     u32 head, len;
     Rec head_rec;
-    __device__ __forceinline__ void push(const EcDev& d, int64_t lane, u32 n_off, Rec rec) {
+    template <class DEV>
+    __device__ __forceinline__ void push(const DEV& d, int64_t lane, u32 n_off, Rec rec) {
         if (len >= (u32)d.capB) {
             flag(d, EC_ST_BUFFER_OVERFLOW);
             return;
@@ -667,7 +766,8 @@ struct Buffer {
         }
         len++;
     }
-    __device__ __forceinline__ Rec pop(const EcDev& d, u32 n_off) {
+    template <class DEV>
+    __device__ __forceinline__ Rec pop(const DEV& d, u32 n_off) {
         Rec r = head_rec;
         r.bwt = r.bwt + (int32_t)n_off;
         head = head + 1 == (u32)d.capB ? 0u : head + 1;
@@ -677,8 +777,8 @@ struct Buffer {
 };
 
 // edge_node.py:159-166 + task.py:6-33
-template <typename RNG>
-__device__ __forceinline__ void generate_task(const EcDev& d, int64_t lane, double qn, double px2, u32 flip,
+template <class DEV, typename RNG>
+__device__ __forceinline__ void generate_task(const DEV& d, int64_t lane, double qn, double px2, u32 flip,
                                               RNG& trng, Buffer& buf, u32 n_off, u32& has_new, Rec& newt) {
     has_new = 0;
     // numpy legacy binomial(1, p): inversion with bound = 1 (see oracle/ec_oracle.c binomial_inversion)
@@ -720,7 +820,8 @@ struct LaneId {
     bool valid;
 };
 // lanes packed contiguously over the block's threads, starting at thread t0
-__device__ __forceinline__ LaneId lane_id(const EcDev& d, int t0 = 0) {
+template <class DEV>
+__device__ __forceinline__ LaneId lane_id(const DEV& d, int t0 = 0) {
     LaneId L;
     const u32 t = threadIdx.x - t0;
     L.env_local = (int)fdiv(t, d.divN);
@@ -733,7 +834,8 @@ __device__ __forceinline__ LaneId lane_id(const EcDev& d, int t0 = 0) {
 }
 // main lanes of k_step: whole envs per wave (d.epw of them) so that a block of several waves keeps the
 // per-wave divergence of a one-wave block; contiguous when one env needs more than a wave
-__device__ __forceinline__ LaneId lane_id_main(const EcDev& d) {
+template <class DEV>
+__device__ __forceinline__ LaneId lane_id_main(const DEV& d) {
     if (d.epw == 0) {
         LaneId L = lane_id(d);
         L.valid = L.valid && (int)threadIdx.x < d.nmain;
@@ -849,7 +951,8 @@ __global__ void k_reset(EcDev d) {
 // LDS scratch: s_full/s_hasnew/s_any [NT] (NT = active lanes), s_obs [NT*9], s_fullbits [epb] or null.
 // With s_fullbits (requires d.adj_bits and every env's lanes consecutive in ONE wave, node 0 first) the "queue
 // full" flags of an env travel as one ballot word and the second barrier + s_any pass are not needed.
-__device__ __forceinline__ void observe_block(const EcDev& d, const LaneId& L, u32 wq_len, double wait_sum, u32 has_new,
+template <class DEV>
+__device__ __forceinline__ void observe_block(const DEV& d, const LaneId& L, u32 wq_len, double wait_sum, u32 has_new,
                                               const Rec& newt, float* __restrict__ obs, int32_t* __restrict__ avail,
                                               u32* s_full, u32* s_hasnew, u32* s_any, float* s_obs, u64* s_fullbits) {
     const int N = d.N, A = d.A;
@@ -1002,7 +1105,6 @@ struct StepPolicy {
     // ec_rollout_random_policy: the kernel takes n_steps steps, each fed by the actions its predecessor drew.
     // keep = 0: every step overwrites the same [B,...] outputs; keep = 1: outputs are [n_steps,B,...] histories.
     int n_steps, keep;
-    unsigned dev_lds;  // looping kernel: LDS byte offset of a block-local copy of the geometry block (0: none)
 };
 
 __device__ __forceinline__ u64 policy_hash(u64 seed, u64 counter, u64 rows, u64 r) {
@@ -1052,7 +1154,8 @@ __device__ __forceinline__ u64 policy_hash(u64 seed, u64 counter, u64 rows, u64 
 // ------------------------------------------------------------------------------------------ expert policy
 // OptimalAgent._calculate_conservative_score (optimal/optimal_agent.py:211-258) with its four terms (:260-375), in
 // the reference's evaluation order (this file is built without FMA contraction).
-__device__ __forceinline__ double expert_score(const EcDev& d, int nwait, int nexec, int s, int t, double size, double cycles,
+template <class DEV>
+__device__ __forceinline__ double expert_score(const DEV& d, int nwait, int nexec, int s, int t, double size, double cycles,
                                                double cons) {
     const double exec_t = cycles / d.cap[t];
     double rel = exp(-d.efr[t] * exec_t);  // :260-289
@@ -1107,8 +1210,8 @@ __device__ __forceinline__ u64 avail_word(const int32_t* __restrict__ a, int A, 
     return m;
 }
 
-template <typename CNT>
-__device__ __forceinline__ int expert_decide(const EcDev& d, int i, const int32_t* __restrict__ a, u32 has_new, double size,
+template <class DEV, typename CNT>
+__device__ __forceinline__ int expert_decide(const DEV& d, int i, const int32_t* __restrict__ a, u32 has_new, double size,
                                              double cycles, CNT cnt) {
     const int nwords = (d.A + 63) >> 6;
     int last = -1;
@@ -1177,8 +1280,8 @@ struct ExpertMix {
 
 // first: the lane's state comes from global memory (else from `cr` and the LDS arrays as the previous step left
 // them); last: it is written back.  One-step launches are both.
-template <int KMAX, int DMAX, bool EVX, int NTC = 0>
-__device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restrict__ actions, float* __restrict__ reward,
+template <int KMAX, int DMAX, bool EVX, int NTC = 0, class DEV = EcDev>
+__device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restrict__ actions, float* __restrict__ reward,
                                           uint8_t* __restrict__ terminated, int32_t* __restrict__ counters,
                                           float* __restrict__ completion_time, float* __restrict__ next_obs,
                                           int32_t* __restrict__ next_avail, StepPolicy pol, StepCarry<KMAX, DMAX>& cr,
@@ -1217,7 +1320,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
         S.cnt = reinterpret_cast<u32*>(p);       p += (size_t)NT * 16;
         S.rc = reinterpret_cast<u32*>(p);        p += (size_t)NT * RC_N * 4;
     }
-    Lut lut{d, (lds_ci16_ptr)S.acc, 0u};
+    Lut<DEV> lut = make_lut(d, (lds_ci16_ptr)S.acc);
 
     // Two roles.  The main lanes (threads < d.nmain) run the env logic and only CONSUME random words.  The RNG
     // producer lanes regenerate the Mersenne-Twister states and stage the step's draws: a wave of their own
@@ -1236,7 +1339,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
 #pragma unroll
         for (int i = 0; i < ACC_LDS / 64; i++) {
             const int a = p0 + i * np;
-            lut_lo[i] = a < ACC_LDS ? reinterpret_cast<const u64*>(d.acc)[a] : 0ull;  // (the table is padded to ACC_LDS_N)
+            lut_lo[i] = a < ACC_LDS ? reinterpret_cast<const u64*>((const int16_t*)d.acc)[a] : 0ull;  // (the table is padded to ACC_LDS_N)
         }
     }
     const int64_t lane = L.lane;
@@ -1521,7 +1624,7 @@ __device__ __forceinline__ void step_body(const EcDev& d, const int64_t* __restr
             const int a = p0 + i * np;
             if (a < ACC_LDS) S.acc[a] = lut_lo[i];
         }
-        for (int a = ACC_LDS + p0; a < d.acc_words; a += np) S.acc[a] = reinterpret_cast<const u64*>(d.acc)[a];  // long episodes
+        for (int a = ACC_LDS + p0; a < d.acc_words; a += np) S.acc[a] = reinterpret_cast<const u64*>((const int16_t*)d.acc)[a];  // long episodes
     }
     if (em && first && L.valid) em->s_cnt[tid] = wq_len | (ex_n << 16);
     EC_STAMP_P(11);
@@ -2463,43 +2566,15 @@ __global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem
 #ifdef EC_STAMPS
     u64 dbg_prev = wall_clock64(), dbg_gap = 0, dbg_body = 0;
 #endif
-    extern __shared__ __align__(16) unsigned char smem_all[];
-    if (pol0.dev_lds) {  // the block's own copy of the geometry block: re-reading it is then not a memory round trip
-        for (int i = threadIdx.x; i < (int)(sizeof(EcDev) / 16); i += blockDim.x)
-            reinterpret_cast<u32x4*>(smem_all + pol0.dev_lds)[i] = reinterpret_cast<const u32x4*>(d_mem)[i];
-        __syncthreads();
-    }
+    // the geometry block in the lanes of three vector registers; its members are read where they are used (see EcDevL)
+    static_assert(DEV_VREGS == 3, "the asm statement below names the registers");
+    u32 dv[DEV_VREGS];
+    dev_lanes_load(dv, d_mem);
     for (int it = 0; it < pol0.n_steps; it++) {
-        size_t opaque = 0;  // an offset the compiler cannot see through: *dp is loaded anew in every iteration
-        asm volatile("" : "+s"(opaque));
-        const EcDev* dp = d_mem + opaque;
-        EcDev d;
-        {   // uniform words: into SGPRs (a plain copy would sit in ~150 VGPRs)
-            static_assert(sizeof(EcDev) % 16 == 0, "EcDev is copied in 16-byte pieces");
-            u32* dst = reinterpret_cast<u32*>(&d);
-            if (pol0.dev_lds) {
-                const u32x4* src = reinterpret_cast<const u32x4*>(smem_all + pol0.dev_lds) + opaque;
-#pragma unroll
-                for (size_t i = 0; i < sizeof(EcDev) / 16; i++) {
-                    const u32x4 v = src[i];
-                    dst[4 * i + 0] = __builtin_amdgcn_readfirstlane(v.x);
-                    dst[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
-                    dst[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z);
-                    dst[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
-                }
-            } else {
-                const u32x4* src = reinterpret_cast<const u32x4*>(dp);
-#pragma unroll
-                for (size_t i = 0; i < sizeof(EcDev) / 16; i++) {
-                    const u32x4 v = src[i];
-                    dst[4 * i + 0] = __builtin_amdgcn_readfirstlane(v.x);
-                    dst[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
-                    dst[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z);
-                    dst[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
-                }
-            }
-        }
-        ec_dev_globalize(d, opaque);
+        // (re-read in every step as far as the compiler can tell: nothing derived from the block is hoisted out of the
+        // loop and kept live across the step, which doubles the step code's spills)
+        asm volatile("" : "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]));
+        const EcDevL d(dv);
         const int64_t hs = pol0.keep ? (int64_t)it : 0;  // history slot of this iteration's outputs
         StepPolicy pol = pol0;
         pol.next_actions += hs * d.P;
@@ -2507,7 +2582,7 @@ __global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem
         const u64 dbg_t0 = wall_clock64();
         dbg_gap += dbg_t0 - dbg_prev;
 #endif
-        step_body<KMAX, DMAX, true, NTC>(d, it == 0 ? actions0 : pol0.next_actions + (pol0.keep ? (int64_t)(it - 1) * d.P : 0),
+        step_body<KMAX, DMAX, true, NTC>(d, it == 0 ? actions0 : pol0.next_actions + (pol0.keep ? (int64_t)(it - 1) * (int64_t)d.P : 0),
                               reward0 ? reward0 + hs * d.B : nullptr, terminated0 ? terminated0 + hs * d.B : nullptr,
                               counters0 ? counters0 + hs * d.B * 4 : nullptr,
                               completion_time0 ? completion_time0 + hs * d.B : nullptr,
@@ -2537,7 +2612,6 @@ struct MlpRollout {
     const int32_t* avail0;  // [B,N,A]
     int n_steps;
     unsigned b23_lds;       // byte offset, past the step's LDS, of the layer-2/3 biases ([64] + [32] f32)
-    unsigned dev_lds;       // byte offset of a block-local copy of the geometry block, or 0: re-read it from global memory
 };
 
 struct ExpertRollout {
@@ -2551,7 +2625,11 @@ template <int TO3, int G>
 __device__ __forceinline__ int rollout_policy_rows(const float* __restrict__ st, const float* s_b23, const float* __restrict__ obs,
                                                    const int32_t* __restrict__ avail, const float* __restrict__ uniforms,
                                                    int64_t* __restrict__ actions, int64_t row0, int cnt, int n_agents, int A,
-                                                   int lane) {
+                                                   int lane POL_ST_ARG) {
+#ifdef EC_STAMPS_POLICY
+    if constexpr (TO3 == 1)
+        if (A <= 16) return polinl::policy_rows<2, G>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane, pst);
+#endif
     if constexpr (TO3 == 1)
         return A <= 16 ? polinl::policy_rows<2, G>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane)
                        : polinl::policy_rows<4, G>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane);
@@ -2569,45 +2647,23 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
     u64 dbg_pol = 0, dbg_wait = 0, dbg_body = 0, dbg_gap = 0, dbg_prev = wall_clock64();
     u64* dbg_out = nullptr;
 #endif
+#ifdef EC_STAMPS_POLICY
+    unsigned long long dbg_ps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define POL_PST , dbg_ps
+#else
+#define POL_PST
+#endif
     extern __shared__ __align__(16) unsigned char smem_all[];
     float* s_b23 = reinterpret_cast<float*>(smem_all + m.b23_lds);
     int* s_pick = reinterpret_cast<int*>(s_b23 + polinl::H + 32 * TO3);  // [main lanes] actions handed over by producer waves
     u32* s_cnt = reinterpret_cast<u32*>(s_pick + d_mem->nmain);    // [main lanes] queue lengths for the expert (EXPERT)
     for (int i = threadIdx.x; i < polinl::H + 32 * TO3; i += blockDim.x) s_b23[i] = m.staged[polinl::off_B2(TO3) + i];
-    if (m.dev_lds)  // the geometry block, re-read every iteration (see k_step): from LDS it is not a memory round trip
-        for (int i = threadIdx.x; i < (int)(sizeof(EcDev) / 16); i += blockDim.x)
-            reinterpret_cast<u32x4*>(smem_all + m.dev_lds)[i] = reinterpret_cast<const u32x4*>(d_mem)[i];
+    u32 dv[DEV_VREGS];  // the geometry block, as in k_step
+    dev_lanes_load(dv, d_mem);
     __syncthreads();
     for (int it = 0; it < m.n_steps; it++) {
-        size_t opaque = 0;
-        asm volatile("" : "+s"(opaque));
-        const EcDev* dp = d_mem + opaque;
-        EcDev d;
-        {
-            u32* dst = reinterpret_cast<u32*>(&d);
-            if (m.dev_lds) {
-                const u32x4* src = reinterpret_cast<const u32x4*>(smem_all + m.dev_lds) + opaque;
-#pragma unroll
-                for (size_t i = 0; i < sizeof(EcDev) / 16; i++) {
-                    const u32x4 v = src[i];
-                    dst[4 * i + 0] = __builtin_amdgcn_readfirstlane(v.x);
-                    dst[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
-                    dst[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z);
-                    dst[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
-                }
-            } else {
-                const u32x4* src = reinterpret_cast<const u32x4*>(dp);
-#pragma unroll
-                for (size_t i = 0; i < sizeof(EcDev) / 16; i++) {
-                    const u32x4 v = src[i];
-                    dst[4 * i + 0] = __builtin_amdgcn_readfirstlane(v.x);
-                    dst[4 * i + 1] = __builtin_amdgcn_readfirstlane(v.y);
-                    dst[4 * i + 2] = __builtin_amdgcn_readfirstlane(v.z);
-                    dst[4 * i + 3] = __builtin_amdgcn_readfirstlane(v.w);
-                }
-            }
-        }
-        ec_dev_globalize(d, opaque);
+        asm volatile("" : "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]));
+        const EcDevL d(dv);
         int64_t* act = actions0 + (int64_t)it * d.P;
         // (see the Actor evaluation below) rows beyond a main wave's first 32 go to the producer waves
         const bool split = (int)blockDim.x > d.nmain && (d.epw > 0 ? d.epw * d.N : 64) > 32;
@@ -2641,7 +2697,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
                 if (cnt > 32) {
                     pick = rollout_policy_rows<TO3, 2>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
                 } else if (cnt > 0) {
-                    pick = rollout_policy_rows<TO3, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
+                    pick = rollout_policy_rows<TO3, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane POL_PST);
                 }
             } else if (split) {
                 for (int w = wave - nmw; w < nmw; w += npw) {  // the remainders of main waves w, w + npw, ...
@@ -2689,6 +2745,9 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
         dbg_out[(size_t)blockIdx.x * 16 + 10] = dbg_wait;
         dbg_out[(size_t)blockIdx.x * 16 + 11] = dbg_body;
         dbg_out[(size_t)blockIdx.x * 16 + 12] = dbg_gap;
+#ifdef EC_STAMPS_POLICY  // (over the last step's phase stamps)
+        for (int i = 0; i < 5; i++) dbg_out[(size_t)blockIdx.x * 16 + i] = dbg_ps[i];
+#endif
     }
 #endif
 }
@@ -2872,13 +2931,10 @@ struct ec_env {
     step_fn step_multi;  // the same kernel looping over steps (ec_rollout_random_policy)
     EcDev* d_dev;        // device copy of `d` for the looping kernel
     bool multi_resident; // every block of the looping kernel fits on the device at once
-    size_t lds_step_multi;   // its dynamic LDS: lds_step + (if it fits) a copy of the geometry block at multi_dev_lds
-    unsigned multi_dev_lds;
     rollout_mlp_fn rollout_mlp;  // looping kernel with the Actor inside (ec_rollout_mlp_policy); null if not compiled for k / D
     rollout_mlp_fn rollout_mlp_expert;  // the same with the expert mixing of the guided runners (ec_rollout_mlp_expert_policy)
     float* d_staged;     // its weight fragments (polinl layout)
     size_t lds_rollout_mlp;
-    unsigned mlp_dev_lds;  // LDS offset of the looping kernel's copy of the geometry block (0: none)
     int kmax, dmax;
     std::vector<void*> allocs;
     size_t state_bytes;
@@ -3249,19 +3305,6 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
         const void* fn_multi = reinterpret_cast<const void*>(h->step_multi);
         EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn_multi, h->threads, h->lds_step));
         h->multi_resident = h->blocks <= (int64_t)per_cu * prop.multiProcessorCount;
-        // + a block-local copy of the geometry block behind the step's LDS, if that does not cost a resident block
-        h->lds_step_multi = h->lds_step;
-        h->multi_dev_lds = 0;
-        const size_t at = (h->lds_step + 15) & ~(size_t)15, more = at + sizeof(EcDev);
-        if (more <= 160 * 1024) {
-            int with = 0;
-            EC_HIP(hipFuncSetAttribute(fn_multi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)more));
-            EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, fn_multi, h->threads, more));
-            if (with == per_cu || h->blocks <= (int64_t)with * prop.multiProcessorCount) {
-                h->multi_dev_lds = (unsigned)at;
-                h->lds_step_multi = more;
-            }
-        }
     }
 #ifdef EC_STAMPS
     EC_TRY(dev_alloc(h, &d.stamps, (size_t)h->blocks * 32, true));  // [0, 16 blocks): phases; then the EC_SUB sums
@@ -3276,21 +3319,6 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
         // (+ another word per main lane: the queue lengths the in-kernel expert reads)
         h->lds_rollout_mlp = ((h->lds_step + 15) & ~(size_t)15) + (polinl::H + 64) * sizeof(float) + 2 * (size_t)d.nmain * sizeof(int);
         if (h->lds_rollout_mlp > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_rollout_mlp);
-        {   // + a copy of the geometry block, if that does not cost a resident block
-            int with = 0, without = 0;
-            const void* fn_mlp = reinterpret_cast<const void*>(h->rollout_mlp);
-            const size_t more = h->lds_rollout_mlp + sizeof(EcDev);
-            h->mlp_dev_lds = 0;
-            if (more <= 160 * 1024) {
-                EC_HIP(hipFuncSetAttribute(fn_mlp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)more));
-                EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&without, fn_mlp, h->threads, h->lds_rollout_mlp));
-                EC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, fn_mlp, h->threads, more));
-                if (with == without || h->blocks <= (int64_t)with * prop.multiProcessorCount) {
-                    h->mlp_dev_lds = (unsigned)h->lds_rollout_mlp;
-                    h->lds_rollout_mlp = more;
-                }
-            }
-        }
         EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->rollout_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lds_rollout_mlp));
         if (h->rollout_mlp_expert)
@@ -3386,9 +3414,8 @@ static int step_impl(ec_handle h, const int64_t* actions, float* reward, uint8_t
     if (!h || !actions) return ec::fail(EC_EINVAL, "null handle or actions");
     EC_ON_DEVICE(h);
     const bool multi = pol.n_steps > 1;
-    pol.dev_lds = multi ? h->multi_dev_lds : 0;
     hipLaunchKernelGGL(multi ? h->step_multi : h->step, dim3((unsigned)h->blocks), dim3(h->threads),
-                       multi ? h->lds_step_multi : h->lds_step, (hipStream_t)stream, h->d, h->d_dev, actions, reward,
+                       h->lds_step, (hipStream_t)stream, h->d, h->d_dev, actions, reward,
                        terminated, counters, completion_time, next_obs, next_avail, pol);
     if (hop_hist) {
         const int64_t n = h->d.B * h->d.H;
@@ -3471,8 +3498,7 @@ static int rollout_mlp_impl(const char* what, ec_handle h, int32_t n_steps, cons
     const int rc = ec::stage_policy(w1, b1, w2, b2, w3, b3, h->d.N, h->d.A, h->d_staged, (hipStream_t)stream);
     if (rc != EC_OK) return rc;
     hipLaunchKernelGGL(fn, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_rollout_mlp, (hipStream_t)stream, h->d_dev,
-                       MlpRollout{h->d_staged, uniforms, obs0, avail0, n_steps, (unsigned)((h->lds_step + 15) & ~(size_t)15),
-                                  h->mlp_dev_lds},
+                       MlpRollout{h->d_staged, uniforms, obs0, avail0, n_steps, (unsigned)((h->lds_step + 15) & ~(size_t)15)},
                        actions, reward, terminated, counters, completion_time, next_obs, next_avail,
                        er ? *er : ExpertRollout{nullptr, nullptr, nullptr});
     if (hop_hist) {

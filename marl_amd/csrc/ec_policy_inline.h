@@ -12,6 +12,22 @@
 
 #include <cstdint>
 
+// diagnostic (EC_STAMPS_POLICY builds, tools/stamps_mlp.py): wall-clock per section of policy_rows, lane 0 of each wave
+#ifdef EC_STAMPS_POLICY
+#define POL_ST(i)                                                  \
+    do {                                                           \
+        if (pst) {                                                 \
+            const unsigned long long now_ = wall_clock64();        \
+            pst[i] += now_ - pst[7];                               \
+            pst[7] = now_;                                         \
+        }                                                          \
+    } while (0)
+#define POL_ST_ARG , unsigned long long* pst = nullptr
+#else
+#define POL_ST(i)
+#define POL_ST_ARG
+#endif
+
 namespace polinl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -100,8 +116,9 @@ template <int NQ, int G, int TO3 = 1>
 __device__ __forceinline__ int policy_rows(const float* __restrict__ st, const float* s_b23,
                                            const float* __restrict__ obs, const int32_t* __restrict__ avail,
                                            const float* __restrict__ uniforms, int64_t* __restrict__ actions,
-                                           int64_t row0, int cnt, int n_agents, int A, int lane) {
+                                           int64_t row0, int cnt, int n_agents, int A, int lane POL_ST_ARG) {
     const int jrow = lane & 31, half = lane >> 5;
+    POL_ST(6);  // (sets the running stamp)
     f32x16 h1[G][2];
     float b[G][5];  // B operand of step s: input k = 2s + half of the group's row (the 10th input is a zero column)
     Frag<4> w1;
@@ -138,6 +155,7 @@ __device__ __forceinline__ int policy_rows(const float* __restrict__ st, const f
             }
         }
     __builtin_amdgcn_sched_barrier(0);
+    POL_ST(0);  // first round trip + layer 1
     // second round, behind layer 2 of the first group: layer 3's fragments and the epilogue's inputs.  Lane l is the
     // lane of row row0 + l (G = 2); lanes 0..31 those of the only group (G = 1)
     if constexpr (TO3 == 1) w3.load(st + F3, 0, lane);
@@ -158,6 +176,7 @@ __device__ __forceinline__ int policy_rows(const float* __restrict__ st, const f
         acc_load<2>(h2, s_b23, half, false);
         hidden_part<2, 0, 8, 0, 16>(h2, w2, h1[g]);
         __builtin_amdgcn_sched_barrier(0);
+        POL_ST(1);  // layer 2
         acc_load<TO3>(lg, s_b23 + H, half, false);
         if constexpr (TO3 == 1) {
             hidden_part<1, 0, 8, 0, 8>(lg, w3, h2);
@@ -168,6 +187,7 @@ __device__ __forceinline__ int policy_rows(const float* __restrict__ st, const f
             hidden_part<2, 0, 4, 0, 8>(lg, wa, h2);
             hidden_part<2, 4, 4, 4, 8>(lg, wb, h2);
         }
+        POL_ST(2);  // layer 3 (+ its fragments' arrival)
         // Output 8q + 4h + c of the group's row j sits in register 4q + c of lane (j, h); the row's lane is (j, 0)
         // for G = 1 and (j, g) for G = 2: it keeps the four outputs of its own half and receives the other four
         // from the lane 32 away.
@@ -183,6 +203,7 @@ __device__ __forceinline__ int policy_rows(const float* __restrict__ st, const f
                 }
             }
         __builtin_amdgcn_sched_barrier(0);
+        POL_ST(3);  // logits exchange
     }
     if (!mine) return -1;
     if constexpr (TO3 == 2) {
@@ -240,6 +261,7 @@ __device__ __forceinline__ int policy_rows(const float* __restrict__ st, const f
         }
     }
     actions[myrow] = pick;
+    POL_ST(4);  // mask + softmax + draw
     return pick;
 }
 

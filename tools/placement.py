@@ -123,3 +123,6 @@ for name, arr in (("between step bodies (end barrier + geometry reload)", gap), 
 for cu in list(blk_by_cu)[:4]:
     print("CU", cu, [(r, "main simd %d slot %d" % (place(s[b, 14])[4], int(s[b, 14]) & 15), "prod simd %d slot %d" % (place(s[b, 15])[4], int(s[b, 15]) & 15),
                      round(body[b] / 60.0, 1)) for r, b in enumerate(sorted(blk_by_cu[cu]))])
+if os.environ.get("STAMPS_BARRIER"):  # -DEC_STAMPS_BARRIER build: slot 13 holds the end-of-step barrier's total instead
+    print("end-of-step barrier alone, us per step by order of block index within the CU:",
+          {r: round(float(np.mean([entry[sorted(bl)[r]] for bl in blk_by_cu.values() if len(bl) > r])) / 100.0 / 60.0, 2) for r in range(4)})
