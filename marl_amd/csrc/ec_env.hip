@@ -2570,7 +2570,12 @@ __global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem
     static_assert(DEV_VREGS == 3, "the asm statement below names the registers");
     u32 dv[DEV_VREGS];
     dev_lanes_load(dv, d_mem);
-    for (int it = 0; it < pol0.n_steps; it++) {
+    // One step.  The launch's first step is a copy of its own ahead of the loop (`first` is a literal at the two call
+    // sites): the loop's copy of the step has no staging code in it, and what a lane carries from step to step then
+    // stays in registers -- with the staging code inside the loop 20 of the carried registers went through scratch
+    // memory at every step boundary (17.26 -> 16.93 us per step, 124 -> 0 B/lane of scratch; peeling the last step as
+    // well: nothing more, twice the code again).
+    const auto one_step = [&](int it, const bool first, const bool last) __attribute__((always_inline)) {
         // (re-read in every step as far as the compiler can tell: nothing derived from the block is hoisted out of the
         // loop and kept live across the step, which doubles the step code's spills)
         asm volatile("" : "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]));
@@ -2582,18 +2587,20 @@ __global__ void __launch_bounds__(256, 2) k_step(EcDev d_arg, const EcDev* d_mem
         const u64 dbg_t0 = wall_clock64();
         dbg_gap += dbg_t0 - dbg_prev;
 #endif
-        step_body<KMAX, DMAX, true, NTC>(d, it == 0 ? actions0 : pol0.next_actions + (pol0.keep ? (int64_t)(it - 1) * (int64_t)d.P : 0),
+        step_body<KMAX, DMAX, true, NTC>(d, first ? actions0 : pol0.next_actions + (pol0.keep ? (int64_t)(it - 1) * (int64_t)d.P : 0),
                               reward0 ? reward0 + hs * d.B : nullptr, terminated0 ? terminated0 + hs * d.B : nullptr,
                               counters0 ? counters0 + hs * d.B * 4 : nullptr,
                               completion_time0 ? completion_time0 + hs * d.B : nullptr,
                               next_obs0 ? next_obs0 + hs * d.P * 9 : nullptr, next_avail0 + hs * d.P * d.A, pol, cr,
-                              it == 0, it + 1 == pol0.n_steps);
+                              first, last);
 #ifdef EC_STAMPS
         dbg_prev = wall_clock64();
         dbg_body += dbg_prev - dbg_t0;
 #endif
         __syncthreads();  // the step is complete in LDS and (RNG cursors, MT words) in this block's global memory
-    }
+    };
+    one_step(0, true, pol0.n_steps == 1);
+    for (int it = 1; it < pol0.n_steps; it++) one_step(it, false, it + 1 == pol0.n_steps);
 #ifdef EC_STAMPS
     if (threadIdx.x == 0 && d_arg.stamps) {  // per block: time between step bodies (barrier + geometry reload) and inside them
         d_arg.stamps[(size_t)blockIdx.x * 16 + 9] = dbg_gap;
@@ -2661,7 +2668,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
     u32 dv[DEV_VREGS];  // the geometry block, as in k_step
     dev_lanes_load(dv, d_mem);
     __syncthreads();
-    for (int it = 0; it < m.n_steps; it++) {
+    const auto one_step = [&](const int it, const bool first) __attribute__((always_inline)) {
         asm volatile("" : "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]));
         const EcDevL d(dv);
         int64_t* act = actions0 + (int64_t)it * d.P;
@@ -2676,8 +2683,8 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
             // Every main wave evaluates the Actor on the rows of its own lanes (lane l of the wave <-> row r0 + l of
             // the block), so the action lands in the lane that takes it: no hand-off and no barrier, and the RNG
             // producer waves go straight into the step to stage its draws while the policy runs.
-            const float* ob = it == 0 ? m.obs0 : next_obs0 + (int64_t)(it - 1) * d.P * 9;
-            const int32_t* av = it == 0 ? m.avail0 : next_avail0 + (int64_t)(it - 1) * d.P * d.A;
+            const float* ob = first ? m.obs0 : next_obs0 + (int64_t)(it - 1) * d.P * 9;
+            const int32_t* av = first ? m.avail0 : next_avail0 + (int64_t)(it - 1) * d.P * d.A;
             const float* un = m.uniforms ? m.uniforms + (int64_t)it * d.P : nullptr;
             int pick = -1;
             const int64_t row_base = (int64_t)blockIdx.x * d.epb * d.N;  // the block's rows are contiguous (lane_id)
@@ -2708,7 +2715,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
                     if (lane < cnt) s_pick[r0 + lane] = pk;  // index = the taking lane's slot (lane_id_main: w * per + l)
                 }
             }
-            if (it > 0) cr.action = pick;  // the first step reads act[] (this lane's own store); split rows: s_pick
+            if (!first) cr.action = pick;  // the first step reads act[] (this lane's own store); split rows: s_pick
         }
 #ifdef EC_STAMPS
         const u64 dbg_t1 = wall_clock64();
@@ -2718,7 +2725,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
         ExpertMix emx;
         const ExpertMix* em = nullptr;
         if (EXPERT) {
-            emx.avail = it == 0 ? m.avail0 : next_avail0 + (int64_t)(it - 1) * d.P * d.A;
+            emx.avail = first ? m.avail0 : next_avail0 + (int64_t)(it - 1) * d.P * d.A;
             emx.coin = er.coin + (int64_t)it * d.B;
             emx.ratio = er.ratios[it];
             emx.expert_out = er.expert_hist + (int64_t)it * d.P;
@@ -2729,7 +2736,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
                                     terminated0 ? terminated0 + hs * d.B : nullptr,
                                     counters0 ? counters0 + hs * d.B * 4 : nullptr,
                                     completion_time0 ? completion_time0 + hs * d.B : nullptr, next_obs0 + hs * d.P * 9,
-                                    next_avail0 + hs * d.P * d.A, StepPolicy{0, 0, nullptr, m.n_steps, 1}, cr, it == 0,
+                                    next_avail0 + hs * d.P * d.A, StepPolicy{0, 0, nullptr, m.n_steps, 1}, cr, first,
                                     it + 1 == m.n_steps, split ? s_pick : nullptr, em);
 #ifdef EC_STAMPS
         dbg_prev = wall_clock64();
@@ -2738,7 +2745,9 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
         dbg_body += dbg_prev - dbg_t2;
 #endif
         __syncthreads();
-    }
+    };
+    // (one copy of the step here: with the first step peeled as in k_step this kernel measured 0.5 us per step slower)
+    for (int it = 0; it < m.n_steps; it++) one_step(it, it == 0);
 #ifdef EC_STAMPS
     if (threadIdx.x == 0 && dbg_out) {  // wave 0's totals: policy tile, wait for the other tiles + action, step, loop gap
         dbg_out[(size_t)blockIdx.x * 16 + 9] = dbg_pol;
