@@ -532,17 +532,43 @@ __device__ __forceinline__ void mt_coop_refill(u32* __restrict__ mt_all, u64 str
                                                u32 want, bool active) {
     const u32 lid = __lane_id();
     unsigned long long need = __ballot(active && ahead < want);
+    // Up to MT_COOP streams (of different lanes) per round: their loads are in flight together, so a round costs one
+    // memory round trip whatever it serves -- the producer wave's regeneration is a chain of such rounds (eleven a step
+    // at one stream per round: the 6.9 us it took from the end of the offload phase were nearly all round trips).
+    constexpr int MT_COOP = 4;
     while (need) {
-        const int o = __ffsll((long long)need) - 1;
-        const u64 ostream = __shfl((unsigned long long)stream_of_lane, o);
-        const u32 opos = __shfl(pos, o), oahead = __shfl(ahead, o);
-        u32* omt = mt_all + ostream * MT_STRIDE;
-        const u32 q = mt_wrap(mt_wrap(opos + oahead) + lid);
-        const u32 cur = omt[q], nxt = omt[mt_wrap(q + 1)], far = omt[mt_wrap(q + MT_M)];
-        const u32 n = mt_next(cur, nxt, far);
-        omt[q] = n;
-        if (q < (u32)MT_MIRROR) omt[q + MT_N] = n;
-        if ((int)lid == o) ahead += 64;
+        int o[MT_COOP];
+        unsigned long long rem = need;
+#pragma unroll
+        for (int u = 0; u < MT_COOP; u++) {
+            o[u] = rem ? __ffsll((long long)rem) - 1 : -1;
+            rem &= rem - 1;
+        }
+        u32 q[MT_COOP], cur[MT_COOP], nxt[MT_COOP], far[MT_COOP];
+        u32* omt[MT_COOP];
+#pragma unroll
+        for (int u = 0; u < MT_COOP; u++) {
+            q[u] = cur[u] = nxt[u] = far[u] = 0;
+            omt[u] = mt_all;
+            if (o[u] >= 0) {  // (wave-uniform)
+                const u64 ostream = __shfl((unsigned long long)stream_of_lane, o[u]);
+                const u32 opos = __shfl(pos, o[u]), oahead = __shfl(ahead, o[u]);
+                omt[u] = mt_all + ostream * MT_STRIDE;
+                q[u] = mt_wrap(mt_wrap(opos + oahead) + lid);
+                cur[u] = omt[u][q[u]];
+                nxt[u] = omt[u][mt_wrap(q[u] + 1)];
+                far[u] = omt[u][mt_wrap(q[u] + MT_M)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MT_COOP; u++) {
+            if (o[u] >= 0) {
+                const u32 n = mt_next(cur[u], nxt[u], far[u]);
+                omt[u][q[u]] = n;
+                if (q[u] < (u32)MT_MIRROR) omt[u][q[u] + MT_N] = n;
+                if ((int)lid == o[u]) ahead += 64;
+            }
+        }
         need = __ballot(active && ahead < want);
     }
 }
