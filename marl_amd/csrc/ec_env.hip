@@ -1103,11 +1103,13 @@ struct StepLds {
     u64* hot;        // [NT] aliases fullbits (dead until phase E): bit i = draw i of the failure window is "hot", i.e.
                      //      its first word reaches d.hot_thr[node] and may fail a test; all other draws fail none
     u32* rc;         // [RC_N][NT] RNG cursors and the producer/consumer hand-off (RC_*)
+    u32* nodec;      // [N][NODEC_W] per-node constants of phases D and E, filed by the launch's first step (looping kernels)
 };
+constexpr int NODEC_W = 16;  // bin_qn, bin_px2, qthr, qlen (doubles), adj_bits (u64), bin_flip (u32), obs_const (3 floats), deg, hot_thr
 enum { RC_FPOS, RC_FAHEAD, RC_TPOS, RC_TAHEAD, RC_FDELTA, RC_TDELTA, RC_DONE, RC_NX, RC_STAGED, RC_FNEXT, RC_PFPOS, RC_PTPOS,
        RC_PSTAGED, RC_N };
-__host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int capW, int acc_words) {
-    size_t b = 0;
+__host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int capW, int acc_words, int n_nodes) {
+    size_t b = (size_t)n_nodes * NODEC_W * 4;
     b += sizeof(double) * acc_words;
     b += (size_t)NT * capW * (16 + 8);
     b += (size_t)NT * KMAX * 8;
@@ -1337,6 +1339,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
         S.tu = reinterpret_cast<double*>(p);     p += (size_t)NT * RB_TASK * 8;
         S.fullbits = reinterpret_cast<u64*>(p);  p += (size_t)NT * 8;
         S.hot = S.fullbits;
+        S.nodec = reinterpret_cast<u32*>(p);     p += (size_t)N * NODEC_W * 4;  // (8-byte aligned here: doubles inside)
         S.fa = reinterpret_cast<u32*>(p);        p += (size_t)NT * (RB_FAIL + 1) * 4;
         S.rqhs = reinterpret_cast<u32*>(p);      p += (size_t)NT * DMAX * 4;
         S.rqhead = reinterpret_cast<u32*>(p);    p += (size_t)NT * DMAX * 4;
@@ -1766,7 +1769,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
             tpos = S.rc[RC_TPOS * NT + ri];
             tah = S.rc[RC_TAHEAD * NT + ri];
             u32 n_ne = 0;
-            const int rdeg = d.deg[R.node];
+            const int rdeg = (EVX && !first) ? (int)S.nodec[R.node * NODEC_W + 14] : d.deg[R.node];
             for (int s = 0; s < rdeg; s++) n_ne += S.rqlen[s * NT + ri] > 0 ? 1u : 0u;
             const u32 nx = S.rc[RC_NX * NT + ri];
             const u32 bound = (u32)d.S * ((nx < (u32)d.k ? nx : (u32)d.k) + n_ne);  // the step's draw bound, as below
@@ -1781,7 +1784,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
                     fv[i] = u32x4{0, 0, 0, 0};
                     if ((u32)(RB_EARLY + 2 * i) < upto) fv[i] = *reinterpret_cast<const u32x4*>(fw + 4 * (i + RB_EARLY / 2));
                 }
-                const u32 hthr = d.hot_thr[R.node];
+                const u32 hthr = (EVX && !first) ? S.nodec[R.node * NODEC_W + 15] : d.hot_thr[R.node];
                 u64 hotm = (u64)((staged1 >> STAGED_HOT_SHIFT) & 0xffffu);
 #pragma unroll
                 for (int i = 0; i < (RB_FAIL - RB_EARLY) / 2; i++) {
@@ -2228,18 +2231,48 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
     u64 o_adjb = 0;
     float o_c0 = 0.0f, o_c1 = 0.0f, o_c2 = 0.0f;
     if (L.valid) {
-        bin_qn = d.bin_qn[node];
-        bin_px2 = d.bin_px2[node];
-        bin_flip = d.bin_flip[node];
         cnt_t = d.rng_cnt[lane];
         cnt_f = d.rng_cnt[P + lane];
-        if (obs_direct) {
-            o_qthr = d.qthr[node];
-            o_qlen = d.qlen[node];
-            o_adjb = d.adj_bits[node];
-            o_c0 = d.obs_const[node * 3 + 0];
-            o_c1 = d.obs_const[node * 3 + 1];
-            o_c2 = d.obs_const[node * 3 + 2];
+        u32* nc = S.nodec + node * NODEC_W;
+        if (EVX && !first) {
+            // a carried step of a looping kernel: the node's constants from the table the first step filed (an LDS read
+            // where the global loads' latency showed: the barrier below is short when the producer wave is done)
+            bin_qn = *reinterpret_cast<const double*>(nc + 0);
+            bin_px2 = *reinterpret_cast<const double*>(nc + 2);
+            bin_flip = nc[10];
+            if (obs_direct) {
+                o_qthr = *reinterpret_cast<const double*>(nc + 4);
+                o_qlen = *reinterpret_cast<const double*>(nc + 6);
+                o_adjb = *reinterpret_cast<const u64*>(nc + 8);
+                o_c0 = __uint_as_float(nc[11]);
+                o_c1 = __uint_as_float(nc[12]);
+                o_c2 = __uint_as_float(nc[13]);
+            }
+        } else {
+            bin_qn = d.bin_qn[node];
+            bin_px2 = d.bin_px2[node];
+            bin_flip = d.bin_flip[node];
+            if (obs_direct) {
+                o_qthr = d.qthr[node];
+                o_qlen = d.qlen[node];
+                o_adjb = d.adj_bits[node];
+                o_c0 = d.obs_const[node * 3 + 0];
+                o_c1 = d.obs_const[node * 3 + 1];
+                o_c2 = d.obs_const[node * 3 + 2];
+            }
+            if (EVX && !last && L.env_local == 0) {  // one env's lanes file the table for the steps that follow
+                *reinterpret_cast<double*>(nc + 0) = bin_qn;
+                *reinterpret_cast<double*>(nc + 2) = bin_px2;
+                *reinterpret_cast<double*>(nc + 4) = o_qthr;
+                *reinterpret_cast<double*>(nc + 6) = o_qlen;
+                *reinterpret_cast<u64*>(nc + 8) = o_adjb;
+                nc[10] = bin_flip;
+                nc[11] = __float_as_uint(o_c0);
+                nc[12] = __float_as_uint(o_c1);
+                nc[13] = __float_as_uint(o_c2);
+                nc[14] = (u32)deg;
+                nc[15] = d.hot_thr[node];
+            }
         }
     }
     double tu0 = 0.0, tu1 = 0.0, tu2 = 0.0, tu3 = 0.0;
@@ -2288,17 +2321,18 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
         // cursor moves by one double, or by four when a task arrives (generate_task's binomial on this step's first
         // double, redone here; a redraw is left to the next step's own part 1, as is a stream not regenerated far enough).
         const int ri = R.lidx;
-        const double U = S.tu[0 * NT + ri], qn = d.bin_qn[R.node];
+        const u32* rnc = S.nodec + R.node * NODEC_W;  // (filed ahead of the barrier above even in the launch's first step)
+        const double U = S.tu[0 * NT + ri], qn = EVX ? *reinterpret_cast<const double*>(rnc + 0) : d.bin_qn[R.node];
         int X = -1;
         if (!(U > qn)) X = 0;
-        else if (!(U - qn > d.bin_px2[R.node])) X = 1;
+        else if (!(U - qn > (EVX ? *reinterpret_cast<const double*>(rnc + 2) : d.bin_px2[R.node]))) X = 1;
         u32 staged_word = 0;
         if (X >= 0) {
-            const u32 arrival = d.bin_flip[R.node] ? 1u - (u32)X : (u32)X;
+            const u32 arrival = (EVX ? rnc[10] : (u32)d.bin_flip[R.node]) ? 1u - (u32)X : (u32)X;
             const u32 fposn = S.rc[RC_FNEXT * NT + ri], tposn = mt_wrap(prod_tpos + (arrival ? 8u : 2u));
             const u32* fw = d.mt + ((size_t)P + (size_t)R.lane) * MT_STRIDE + fposn;  // wrap-free thanks to the mirror
             const u32* tw = d.mt + (size_t)R.lane * MT_STRIDE + tposn;
-            const u32 hthr = d.hot_thr[R.node];
+            const u32 hthr = EVX ? rnc[15] : d.hot_thr[R.node];
             u32x4 fv[RB_EARLY / 2];
 #pragma unroll
             for (int i = 0; i < RB_EARLY / 2; i++) fv[i] = *reinterpret_cast<const u32x4*>(fw + 4 * i);
@@ -3259,7 +3293,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     };
     // rounds: how many times over the launch's blocks exceed what the device holds at once (0: does not fit a block)
     auto geo_fits = [&](const Geo& g, size_t* lds_out, bool* resident, int64_t* rounds) -> int {
-        const size_t lds = step_lds_bytes(g.epb() * N, h->kmax, h->dmax, d.capW, d.acc_words);
+        const size_t lds = step_lds_bytes(g.epb() * N, h->kmax, h->dmax, d.capW, d.acc_words, N);
         *lds_out = lds;
         *resident = false;
         *rounds = 0;
@@ -3330,7 +3364,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     h->envs_per_block = epb;
     h->blocks = (B + epb - 1) / epb;
     h->lds_obs = (size_t)epb * N * (3 * 4 + 9 * 4);
-    h->lds_step = step_lds_bytes(epb * N, h->kmax, h->dmax, d.capW, d.acc_words);
+    h->lds_step = step_lds_bytes(epb * N, h->kmax, h->dmax, d.capW, d.acc_words, N);
     if (h->lds_step > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_step);
     EC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
     EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->step_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
