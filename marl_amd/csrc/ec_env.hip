@@ -116,7 +116,7 @@ struct alignas(16) EcDev {
     FastDiv divN, divA;
     int fast_dl;   // the host has checked the bound behind Lut::deadline_ticks' closed form (see build())
     int acc_words; // 8-byte words of LDS holding the tick LUT: all of it (>= ACC_LDS, 4 entries per word)
-    int pad_;
+    int link_lds;  // the looping kernels keep the out-link tables (slot, rate) in LDS (small topologies: N <= LINK_LDS_N)
     int64_t B, P;
     // scalars
     double dt, inv_dt, deadline;
@@ -236,6 +236,7 @@ struct EcDevL {
     DevField<decltype(EcDev::divA), offsetof(EcDev, divA)> divA;
     DevField<decltype(EcDev::fast_dl), offsetof(EcDev, fast_dl)> fast_dl;
     DevField<decltype(EcDev::acc_words), offsetof(EcDev, acc_words)> acc_words;
+    DevField<decltype(EcDev::link_lds), offsetof(EcDev, link_lds)> link_lds;
     DevField<decltype(EcDev::B), offsetof(EcDev, B)> B;
     DevField<decltype(EcDev::P), offsetof(EcDev, P)> P;
     DevField<decltype(EcDev::dt), offsetof(EcDev, dt)> dt;
@@ -302,7 +303,7 @@ struct EcDevL {
     __device__ __forceinline__ explicit EcDevL(const u32 (&v_)[DEV_VREGS])
         : N{v_}, A{v_}, k{v_}, D{v_}, S{v_}, T{v_}, H{v_}, capB{v_},
           capR{v_}, capW{v_}, maxTicks{v_}, epb{v_}, epw{v_}, nmain{v_}, dl_ticks{v_}, divN{v_},
-          divA{v_}, fast_dl{v_}, acc_words{v_}, B{v_}, P{v_}, dt{v_}, inv_dt{v_}, deadline{v_},
+          divA{v_}, fast_dl{v_}, acc_words{v_}, link_lds{v_}, B{v_}, P{v_}, dt{v_}, inv_dt{v_}, deadline{v_},
           size_lo{v_}, size_range{v_}, cx_lo{v_}, cx_range{v_}, pen_drop{v_}, pen_fail{v_}, rew_succ{v_}, pen_hop{v_},
           obs_size_norm{v_}, obs_cyc_norm{v_}, acc{v_}, cap{v_}, thr_exec_m{v_}, hot_thr{v_}, qlen{v_}, qthr{v_},
           obs_const{v_}, bin_qn{v_}, bin_px2{v_}, bin_flip{v_}, deg{v_}, in_src{v_}, thr_link_m{v_}, slot_of{v_},
@@ -1104,11 +1105,19 @@ struct StepLds {
                      //      its first word reaches d.hot_thr[node] and may fail a test; all other draws fail none
     u32* rc;         // [RC_N][NT] RNG cursors and the producer/consumer hand-off (RC_*)
     u32* nodec;      // [N][NODEC_W] per-node constants of phases D and E, filed by the launch's first step (looping kernels)
+    double* linkr;   // [N][DMAX] rate of the link into node n from its s-th in-neighbour   } N <= LINK_LDS_N: the offload
+    signed char* slotb;  // [N][N] slot of src in dst's in-list, -1 if not adjacent          } phase's look-ups, as nodec
 };
+constexpr int LINK_LDS_N = 16;
 constexpr int NODEC_W = 16;  // bin_qn, bin_px2, qthr, qlen (doubles), adj_bits (u64), bin_flip (u32), obs_const (3 floats), deg, hot_thr
 enum { RC_FPOS, RC_FAHEAD, RC_TPOS, RC_TAHEAD, RC_FDELTA, RC_TDELTA, RC_DONE, RC_NX, RC_STAGED, RC_FNEXT, RC_PFPOS, RC_PTPOS,
        RC_PSTAGED, RC_N };
-__host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int capW, int acc_words, int n_nodes) {
+__host__ __device__ inline size_t link_lds_bytes(int DMAX, int n_nodes) {
+    return n_nodes <= LINK_LDS_N ? (size_t)n_nodes * DMAX * 8 + (((size_t)n_nodes * n_nodes + 7) & ~(size_t)7) : 0;
+}
+// n_nodes_links > 0: with the link tables (k_rollout_mlp's launches)
+__host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int capW, int acc_words, int n_nodes,
+                                                 int n_nodes_links = 0) {
     size_t b = (size_t)n_nodes * NODEC_W * 4;
     b += sizeof(double) * acc_words;
     b += (size_t)NT * capW * (16 + 8);
@@ -1117,6 +1126,8 @@ __host__ __device__ inline size_t step_lds_bytes(int NT, int KMAX, int DMAX, int
     b += (size_t)NT * (RB_FAIL + 1) * 4;
     b += (size_t)NT * (8 + 8 + 16);
     b += (size_t)NT * (RB_TASK * 8 + RC_N * 4 + 8);
+    b = (b + 7) & ~(size_t)7;
+    if (n_nodes_links > 0) b += (link_lds_bytes(DMAX, n_nodes_links) + 15) & ~(size_t)15;
     return b + 64;
 }
 
@@ -1348,6 +1359,10 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
         S.rqarr = reinterpret_cast<u32*>(p);     p += (size_t)NT * DMAX * 4;
         S.cnt = reinterpret_cast<u32*>(p);       p += (size_t)NT * 16;
         S.rc = reinterpret_cast<u32*>(p);        p += (size_t)NT * RC_N * 4;
+        // (the link tables last, 8-byte aligned: only k_rollout_mlp's launches have them)
+        p = smem + (((size_t)(p - smem) + 7) & ~(size_t)7);
+        S.linkr = reinterpret_cast<double*>(p);
+        S.slotb = reinterpret_cast<signed char*>(p + (N <= LINK_LDS_N ? (size_t)N * DMAX * 8 : 0));
     }
     Lut<DEV> lut = make_lut(d, (lds_ci16_ptr)S.acc);
 
@@ -1373,6 +1388,18 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
     }
     const int64_t lane = L.lane;
     const int node = L.node;
+    // the out-link of an action: slot of this node in the destination's in-list and the link's rate -- in carried steps of
+    // the looping kernels from the LDS tables the first step filed (small topologies), else from global memory
+    const bool link_lds = EVX && !first && (s_pick != nullptr || em != nullptr) && d.link_lds;
+    const auto link_of = [&](int a, int& sl, double& rt) {
+        if (link_lds) {
+            sl = (int)S.slotb[node * N + a];
+            rt = sl >= 0 ? S.linkr[a * DMAX + sl] : 0.0;
+        } else {
+            sl = d.slot_of[node * N + a];
+            rt = d.rate[node * N + a];
+        }
+    };
     EC_STAMP(0);
 
     // ---------------------------------------------------------------- stage the lane's working set
@@ -1437,10 +1464,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
             exh[s] = cr.exh[s];
             exT[s] = cr.exT[s];
         }
-        if (has_new && action >= 0 && action < N && action != node) {
-            slot = d.slot_of[node * N + (int)action];
-            rate = d.rate[node * N + (int)action];
-        }
+        if (has_new && action >= 0 && action < N && action != node) link_of((int)action, slot, rate);
     }
     if (L.valid && first) {
         c0 = d.tick[L.env];
@@ -1665,10 +1689,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
         action = s_pick[tid];
         slot = -1;
         rate = 0.0;
-        if (has_new && action >= 0 && action < N && action != node) {
-            slot = d.slot_of[node * N + (int)action];
-            rate = d.rate[node * N + (int)action];
-        }
+        if (has_new && action >= 0 && action < N && action != node) link_of((int)action, slot, rate);
     }
 
     if (em && L.valid) {
@@ -1684,10 +1705,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
             action = ea;
             slot = -1;
             rate = 0.0;
-            if (has_new && action >= 0 && action < N && action != node) {
-                slot = d.slot_of[node * N + (int)action];
-                rate = d.rate[node * N + (int)action];
-            }
+            if (has_new && action >= 0 && action < N && action != node) link_of((int)action, slot, rate);
         }
     }
 
@@ -2272,6 +2290,10 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
                 nc[13] = __float_as_uint(o_c2);
                 nc[14] = (u32)deg;
                 nc[15] = d.hot_thr[node];
+                if ((s_pick != nullptr || em != nullptr) && d.link_lds) {
+                    for (int a = 0; a < N; a++) S.slotb[node * N + a] = (signed char)d.slot_of[node * N + a];
+                    for (int q = 0; q < deg; q++) S.linkr[node * DMAX + q] = d.rate[d.in_src[node * D + q] * N + node];
+                }
             }
         }
     }
@@ -3007,6 +3029,7 @@ struct ec_env {
     int threads_obs;  // block size of k_observe (the block's lanes, contiguous)
     int64_t blocks;
     size_t lds_step, lds_obs;
+    size_t lds_step_links;  // lds_step + the link tables (k_rollout_mlp)
     step_fn step;        // one env step per launch
     step_fn step_multi;  // the same kernel looping over steps (ec_rollout_random_policy)
     EcDev* d_dev;        // device copy of `d` for the looping kernel
@@ -3212,7 +3235,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
         if (n_ent < (size_t)ACC_LDS_N) n_ent = ACC_LDS_N;
         n_ent = (n_ent + 3) & ~(size_t)3;
         d.acc_words = (int)(n_ent / 4);
-        d.pad_ = 0;
+        d.link_lds = N <= LINK_LDS_N ? 1 : 0;
         std::vector<int16_t> corr(n_ent, 0);
         for (int n = 0; n <= d.maxTicks; n++) {
             const double prod = (double)n * cfg->mini_time_slot;
@@ -3376,6 +3399,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     h->blocks = (B + epb - 1) / epb;
     h->lds_obs = (size_t)epb * N * (3 * 4 + 9 * 4);
     h->lds_step = step_lds_bytes(epb * N, h->kmax, h->dmax, d.capW, d.acc_words, N);
+    h->lds_step_links = step_lds_bytes(epb * N, h->kmax, h->dmax, d.capW, d.acc_words, N, N);
     if (h->lds_step > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_step);
     EC_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
     EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->step_multi), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3397,7 +3421,7 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
     if (h->rollout_mlp) {
         // + layer-2/3 biases + one action word per main lane (the producer waves' share of the Actor rows)
         // (+ another word per main lane: the queue lengths the in-kernel expert reads)
-        h->lds_rollout_mlp = ((h->lds_step + 15) & ~(size_t)15) + (polinl::H + 64) * sizeof(float) + 2 * (size_t)d.nmain * sizeof(int);
+        h->lds_rollout_mlp = ((h->lds_step_links + 15) & ~(size_t)15) + (polinl::H + 64) * sizeof(float) + 2 * (size_t)d.nmain * sizeof(int);
         if (h->lds_rollout_mlp > 160 * 1024) return ec::fail(EC_EINVAL, "LDS need %zu exceeds 160 KiB", h->lds_rollout_mlp);
         EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(h->rollout_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->lds_rollout_mlp));
@@ -3578,7 +3602,7 @@ static int rollout_mlp_impl(const char* what, ec_handle h, int32_t n_steps, cons
     const int rc = ec::stage_policy(w1, b1, w2, b2, w3, b3, h->d.N, h->d.A, h->d_staged, (hipStream_t)stream);
     if (rc != EC_OK) return rc;
     hipLaunchKernelGGL(fn, dim3((unsigned)h->blocks), dim3(h->threads), h->lds_rollout_mlp, (hipStream_t)stream, h->d_dev,
-                       MlpRollout{h->d_staged, uniforms, obs0, avail0, n_steps, (unsigned)((h->lds_step + 15) & ~(size_t)15)},
+                       MlpRollout{h->d_staged, uniforms, obs0, avail0, n_steps, (unsigned)((h->lds_step_links + 15) & ~(size_t)15)},
                        actions, reward, terminated, counters, completion_time, next_obs, next_avail,
                        er ? *er : ExpertRollout{nullptr, nullptr, nullptr});
     if (hop_hist) {
