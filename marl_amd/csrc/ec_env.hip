@@ -1683,6 +1683,32 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
     EC_STAMP_P(11);
     __syncthreads();
     EC_STAMP(1);
+    if (EVX && has_producers && producer_wave && R.valid) {
+        // Looping kernels: the rest of the failure window NOW, while the main lanes are in the offload phase and this wave
+        // would wait at the next barrier -- all of it (the stream is regenerated a whole window ahead of the cursor; the
+        // step's draw bound, known only behind that barrier, merely says how much of it can be used).  Part 2 below is
+        // then regeneration only, and a busy lane finds its 17th draw staged when the mini-slots begin.
+        const int ri = R.lidx;
+        const u32 staged1 = S.rc[RC_STAGED * NT + ri];
+        if (!(staged1 & STAGED_FINAL)) {
+            const u32* fw = d.mt + ((size_t)P + (size_t)R.lane) * MT_STRIDE + S.rc[RC_FPOS * NT + ri];
+            u32x4 fv[(RB_FAIL - RB_EARLY) / 2];
+#pragma unroll
+            for (int i = 0; i < (RB_FAIL - RB_EARLY) / 2; i++) fv[i] = *reinterpret_cast<const u32x4*>(fw + 4 * (i + RB_EARLY / 2));
+            const u32 hthr = !first ? S.nodec[R.node * NODEC_W + 15] : d.hot_thr[R.node];
+            u64 hotm = (u64)((staged1 >> STAGED_HOT_SHIFT) & 0xffffu);
+#pragma unroll
+            for (int i = 0; i < (RB_FAIL - RB_EARLY) / 2; i++) {
+                const u32 a0 = mt_temper(fv[i].x) >> 5, a1 = mt_temper(fv[i].z) >> 5;
+                S.fa[(RB_EARLY + 2 * i) * NT + ri] = a0;
+                S.fa[(RB_EARLY + 2 * i + 1) * NT + ri] = a1;
+                hotm |= (u64)(a0 >= hthr ? 1u : 0u) << (RB_EARLY + 2 * i);
+                hotm |= (u64)(a1 >= hthr ? 1u : 0u) << (RB_EARLY + 2 * i + 1);
+            }
+            S.hot[ri] = hotm;
+            S.rc[RC_STAGED * NT + ri] = (u32)RB_FAIL | STAGED_FINAL;  // (published by the barrier behind the offload phase)
+        }
+    }
     // ec_rollout_mlp_policy: the Actor rows beyond a main wave's first 32 were evaluated by a producer wave, which left
     // the actions in LDS ahead of this barrier (k_rollout_mlp)
     if (s_pick && L.valid && (threadIdx.x & 63u) >= 32u) {
@@ -2355,37 +2381,26 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
             const u32* fw = d.mt + ((size_t)P + (size_t)R.lane) * MT_STRIDE + fposn;  // wrap-free thanks to the mirror
             const u32* tw = d.mt + (size_t)R.lane * MT_STRIDE + tposn;
             const u32 hthr = EVX ? rnc[15] : d.hot_thr[R.node];
-            // the WHOLE window (the stream is regenerated a window ahead of the cursor at every step boundary, which the
-            // next step's part 1 checks before it takes any of this): the next step's part 2 is then regeneration only,
-            // and a busy lane never waits for draws beyond the first RB_EARLY
-            static_assert(RB_FAIL % 4 == 0, "the window is staged in two halves");
-            constexpr int HW = RB_FAIL / 4;  // 16-byte pieces per half (two rounds: a register budget, not a latency one)
+            u32x4 fv[RB_EARLY / 2];
+#pragma unroll
+            for (int i = 0; i < RB_EARLY / 2; i++) fv[i] = *reinterpret_cast<const u32x4*>(fw + 4 * i);
             const u32x4 t0 = *reinterpret_cast<const u32x4*>(tw), t1 = *reinterpret_cast<const u32x4*>(tw + 4);
-            u64 hotm = 0;
+            u32 hot16 = 0;
 #pragma unroll
-            for (int hf = 0; hf < 2; hf++) {
-                u32x4 fv[HW];
-#pragma unroll
-                for (int i = 0; i < HW; i++) fv[i] = *reinterpret_cast<const u32x4*>(fw + 4 * (hf * HW + i));
-#pragma unroll
-                for (int i = 0; i < HW; i++) {
-                    const int j = hf * HW + i;
-                    const u32 a0 = mt_temper(fv[i].x) >> 5, a1 = mt_temper(fv[i].z) >> 5;
-                    S.fa[(2 * j) * NT + ri] = a0;
-                    S.fa[(2 * j + 1) * NT + ri] = a1;
-                    hotm |= (u64)(a0 >= hthr ? 1u : 0u) << (2 * j);
-                    hotm |= (u64)(a1 >= hthr ? 1u : 0u) << (2 * j + 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < RB_EARLY / 2; i++) {
+                const u32 a0 = mt_temper(fv[i].x) >> 5, a1 = mt_temper(fv[i].z) >> 5;
+                S.fa[(2 * i) * NT + ri] = a0;
+                S.fa[(2 * i + 1) * NT + ri] = a1;
+                hot16 |= (a0 >= hthr ? 1u : 0u) << (2 * i);
+                hot16 |= (a1 >= hthr ? 1u : 0u) << (2 * i + 1);
             }
-            S.hot[ri] = hotm;  // (dead since the mini-slots: phase E in its direct form keeps the "queue full" bits in registers)
             S.tu[0 * NT + ri] = mt_to_double(t0.x, t0.y);
             S.tu[1 * NT + ri] = mt_to_double(t0.z, t0.w);
             S.tu[2 * NT + ri] = mt_to_double(t1.x, t1.y);
             S.tu[3 * NT + ri] = mt_to_double(t1.z, t1.w);
             S.rc[RC_PFPOS * NT + ri] = fposn;
             S.rc[RC_PTPOS * NT + ri] = tposn;
-            staged_word = (u32)RB_FAIL | STAGED_FINAL;
+            staged_word = (u32)RB_EARLY | (hot16 << STAGED_HOT_SHIFT);
         }
         S.rc[RC_PSTAGED * NT + ri] = staged_word;
     }
