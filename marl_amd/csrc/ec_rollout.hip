@@ -105,6 +105,7 @@ struct EpisodeArgs {
     double* partial;   // [T,6] scratch
     uint32_t* done;    // zero on entry, zero again on exit
     int64_t copy_blocks;
+    int vec2;          // the copy part moves 8-byte pieces (even N*O and N*A, 8-byte aligned bases)
 };
 
 constexpr int EP_TC = 10;  // steps per copy block of k_store_episode
@@ -118,6 +119,80 @@ __global__ void __launch_bounds__(256) k_store_episode(EpisodeArgs a) {
         const int64_t t0 = ((int64_t)blockIdx.x - b * chunks) * EP_TC;
         const int nt = (int)(a.T - t0 < EP_TC ? a.T - t0 : EP_TC);
         const int NO = a.N * a.O, NA = a.N * a.A;
+        if (a.vec2) {
+            // N*O and N*A even, every base 8-byte aligned (the launcher checked): a wave takes a step at a time and copies
+            // each of its segments as 8-byte pieces -- no index division per element, half the memory instructions
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+            const int NO2 = NO >> 1, NA2 = NA >> 1;
+            if (NO2 <= 64 && NA2 <= 64 && a.N <= 64 && nw * 3 >= EP_TC) {
+                // (the path's shapes: a segment is at most one piece per lane; the wave's up to three steps are loaded
+                // before any is stored, so their round trips overlap)
+                float2 vo[3], vp[3];
+                int2 va[3];
+                int64_t ac[3];
+                float rw[3], mk[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int tt = wave + u * nw;
+                    vo[u] = vp[u] = make_float2(0.0f, 0.0f);
+                    va[u] = make_int2(0, 0);
+                    ac[u] = 0;
+                    rw[u] = mk[u] = 0.0f;
+                    if (tt < nt) {
+                        const int64_t t = t0 + tt;
+                        if (lane < NO2) {
+                            vo[u] = reinterpret_cast<const float2*>(a.h_obs + (t * a.B + b) * NO)[lane];
+                            vp[u] = reinterpret_cast<const float2*>(t == 0 ? a.obs0 + b * NO : a.h_obs + ((t - 1) * a.B + b) * NO)[lane];
+                        }
+                        if (lane < NA2)
+                            va[u] = reinterpret_cast<const int2*>(t == 0 ? a.avail0 + b * NA : a.h_avail + ((t - 1) * a.B + b) * NA)[lane];
+                        if (lane < a.N) ac[u] = a.h_actions[(t * a.B + b) * a.N + lane];
+                        rw[u] = a.h_reward[t * a.B + b];
+                        mk[u] = a.h_term[t * a.B + b] ? 0.0f : 1.0f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int tt = wave + u * nw;
+                    if (tt < nt) {
+                        const int64_t row = b * a.T + t0 + tt;
+                        if (lane < NO2) {
+                            reinterpret_cast<float2*>(a.b_next_obs + row * NO)[lane] = vo[u];
+                            reinterpret_cast<float2*>(a.b_obs + row * NO)[lane] = vp[u];
+                        }
+                        if (lane < NA2) reinterpret_cast<int2*>(a.b_avail + row * NA)[lane] = va[u];
+                        if (lane < a.N) {
+                            a.b_actions[row * a.N + lane] = ac[u];
+                            a.b_rewards[row * a.N + lane] = rw[u];  // team reward, parallel_episode_runner.py:101
+                            a.b_masks[row * a.N + lane] = mk[u];    // :102
+                        }
+                    }
+                }
+                return;
+            }
+            for (int tt = wave; tt < nt; tt += nw) {
+                const int64_t t = t0 + tt, row = b * a.T + t;
+                const float2* so = reinterpret_cast<const float2*>(a.h_obs + (t * a.B + b) * NO);
+                const float2* sp = reinterpret_cast<const float2*>(t == 0 ? a.obs0 + b * NO : a.h_obs + ((t - 1) * a.B + b) * NO);
+                const int2* sa = reinterpret_cast<const int2*>(t == 0 ? a.avail0 + b * NA : a.h_avail + ((t - 1) * a.B + b) * NA);
+                float2* dn = reinterpret_cast<float2*>(a.b_next_obs + row * NO);
+                float2* dp = reinterpret_cast<float2*>(a.b_obs + row * NO);
+                int2* da = reinterpret_cast<int2*>(a.b_avail + row * NA);
+                for (int k = lane; k < NO2; k += 64) {
+                    dn[k] = so[k];
+                    dp[k] = sp[k];
+                }
+                for (int k = lane; k < NA2; k += 64) da[k] = sa[k];
+                const float rw = a.h_reward[t * a.B + b];                       // team reward, parallel_episode_runner.py:101
+                const float mk = a.h_term[t * a.B + b] ? 0.0f : 1.0f;           // :102
+                for (int n = lane; n < a.N; n += 64) {
+                    a.b_actions[row * a.N + n] = a.h_actions[(t * a.B + b) * a.N + n];
+                    a.b_rewards[row * a.N + n] = rw;
+                    a.b_masks[row * a.N + n] = mk;
+                }
+            }
+            return;
+        }
         for (int i = threadIdx.x; i < nt * NO; i += blockDim.x) {
             const int tt = i / NO, k = i - tt * NO;
             const int64_t t = t0 + tt, dst = (b * a.T + t) * NO + k;
@@ -191,9 +266,12 @@ int store_episode_launch(const char* who, const float* obs0, const int32_t* avai
     const int64_t blocks = copy_blocks + (totals ? episode_limit : 0);
     if (blocks == 0) return EC_OK;
     if (blocks > 0x7fffffffll) return ec::fail(EC_EINVAL, "%s: %lld blocks", who, (long long)blocks);
+    const auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+    const int vec2 = buf_obs && (n_agents * obs_dim) % 2 == 0 && (n_agents * n_actions) % 2 == 0 && al8(obs0) && al8(avail0) &&
+                     al8(hist_obs) && al8(hist_avail) && al8(buf_obs) && al8(buf_avail) && al8(buf_next_obs);
     EpisodeArgs a{obs0, avail0, hist_obs, hist_avail, hist_actions, hist_reward, hist_terminated, hist_counters,
                   hist_completion_time, n_envs, n_agents, obs_dim, n_actions, episode_limit, buf_obs, buf_avail,
-                  buf_actions, buf_rewards, buf_masks, buf_next_obs, totals, partial, done, copy_blocks};
+                  buf_actions, buf_rewards, buf_masks, buf_next_obs, totals, partial, done, copy_blocks, vec2};
     hipLaunchKernelGGL(k_store_episode, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     EC_HIP(hipGetLastError());
     return EC_OK;
