@@ -108,7 +108,8 @@ struct EpisodeArgs {
     int vec2;          // the copy part moves 8-byte pieces (even N*O and N*A, 8-byte aligned bases)
 };
 
-constexpr int EP_TC = 10;  // steps per copy block of k_store_episode
+constexpr int EP_TC = 20;  // steps per copy block of k_store_episode
+constexpr int EP_U = 5;    // steps per wave of a 4-wave block in its vector path
 
 __global__ void __launch_bounds__(256) k_store_episode(EpisodeArgs a) {
     if ((int64_t)blockIdx.x < a.copy_blocks) {
@@ -124,15 +125,15 @@ __global__ void __launch_bounds__(256) k_store_episode(EpisodeArgs a) {
             // each of its segments as 8-byte pieces -- no index division per element, half the memory instructions
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
             const int NO2 = NO >> 1, NA2 = NA >> 1;
-            if (NO2 <= 64 && NA2 <= 64 && a.N <= 64 && nw * 3 >= EP_TC) {
-                // (the path's shapes: a segment is at most one piece per lane; the wave's up to three steps are loaded
+            if (NO2 <= 64 && NA2 <= 64 && a.N <= 64 && nw * EP_U >= EP_TC) {
+                // (the path's shapes: a segment is at most one piece per lane; the wave's up to EP_U steps are loaded
                 // before any is stored, so their round trips overlap)
-                float2 vo[3], vp[3];
-                int2 va[3];
-                int64_t ac[3];
-                float rw[3], mk[3];
+                float2 vo[EP_U], vp[EP_U];
+                int2 va[EP_U];
+                int64_t ac[EP_U];
+                float rw[EP_U], mk[EP_U];
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
+                for (int u = 0; u < EP_U; u++) {
                     const int tt = wave + u * nw;
                     vo[u] = vp[u] = make_float2(0.0f, 0.0f);
                     va[u] = make_int2(0, 0);
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(256) k_store_episode(EpisodeArgs a) {
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
+                for (int u = 0; u < EP_U; u++) {
                     const int tt = wave + u * nw;
                     if (tt < nt) {
                         const int64_t row = b * a.T + t0 + tt;
