@@ -2871,11 +2871,20 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
 
 typedef void (*rollout_mlp_fn)(const EcDev*, MlpRollout, int64_t*, float*, uint8_t*, int32_t*, float*, float*, int32_t*,
                                ExpertRollout);
-constexpr int NT_DEFAULT = 40;  // lanes per block of the default size's geometry (4 envs x 10 nodes): specialised instantiations
+#ifndef EC_NT_DEFAULT
+#define EC_NT_DEFAULT 40
+#endif
+constexpr int NT_DEFAULT = EC_NT_DEFAULT;  // lanes per block of the default size's geometry (4 envs x 10 nodes): specialised instantiations
 rollout_mlp_fn pick_rollout_mlp(int k, int D, int A, bool expert, int nt) {  // the common shapes only: every instantiation is a full step kernel
     if (k > 4 || A > 64) return nullptr;
     if (nt == NT_DEFAULT && A <= 32 && D <= 4)
         return expert ? k_rollout_mlp<4, 4, true, 1, NT_DEFAULT> : k_rollout_mlp<4, 4, false, 1, NT_DEFAULT>;
+#ifndef EC_DEV_BUILD
+    // (the geometries a 10-node job takes at 1 / 2 envs per block: up to 1024 / 2048 envs per GPU, the shards of a
+    // multi-GPU run; 5 % per step at 1024 envs)
+    if (nt == 10 && A <= 32 && D <= 4) return expert ? k_rollout_mlp<4, 4, true, 1, 10> : k_rollout_mlp<4, 4, false, 1, 10>;
+    if (nt == 20 && A <= 32 && D <= 4) return expert ? k_rollout_mlp<4, 4, true, 1, 20> : k_rollout_mlp<4, 4, false, 1, 20>;
+#endif
 #ifdef EC_DEV_BUILD
     if (A > 32 || D > 4) return nullptr;
     return expert ? k_rollout_mlp<4, 4, true, 1> : k_rollout_mlp<4, 4, false, 1>;
@@ -2900,6 +2909,10 @@ template <bool MULTI>
 step_fn pick_step(int k, int D, int* kmax, int* dmax, int nt = 0) {
     *dmax = D <= 4 ? 4 : 8;
     if (k <= 4 && D <= 4 && nt == NT_DEFAULT) return *kmax = 4, k_step<4, 4, MULTI, NT_DEFAULT>;
+#ifndef EC_DEV_BUILD
+    if (k <= 4 && D <= 4 && nt == 10) return *kmax = 4, k_step<4, 4, MULTI, 10>;
+    if (k <= 4 && D <= 4 && nt == 20) return *kmax = 4, k_step<4, 4, MULTI, 20>;
+#endif
     if (k <= 4) return *kmax = 4, pick_step_d<4, MULTI>(D);
 #ifndef EC_DEV_BUILD
     if (k <= 8) return *kmax = 8, pick_step_d<8, MULTI>(D);
