@@ -3392,6 +3392,21 @@ int build(ec_env* h, const ec_config* cfg, const ec_topology* topo, int64_t B, i
         const int epw_max = 64 / N;
         Geo best{epw_max, 1, 0};
         int64_t best_rounds = 0;
+        // First: a block per CU at most, with the fewest envs per wave that allows it.  Blocks that share a CU slow each
+        // other down by more than the extra lanes of a fuller wave cost (512 envs x 10 nodes: 256 blocks of 2 envs
+        // 12.5 us per step, 512 blocks of 1 env 13.4; 1024 envs: 256 blocks of 4 envs = 1024 blocks of 1 env).
+        for (int epw = 1; want_producers && epw <= epw_max && !found; epw++) {
+            Geo g{epw, 1, (epw * N + 63) / 64};
+            if ((B + g.epb() - 1) / g.epb() > prop.multiProcessorCount) continue;
+            size_t lds;
+            bool resident;
+            int64_t rounds;
+            EC_TRY(geo_fits(g, &lds, &resident, &rounds));
+            if (resident) {
+                geo = g;
+                found = true;
+            }
+        }
         for (int pass = want_producers ? 0 : 1; pass < 2 && !found; pass++) {  // pass 0: with producer waves
             for (int epw = 1; epw <= epw_max && !found; epw++) {
                 for (int mw = 1; mw <= 4 && !found; mw++) {
