@@ -727,7 +727,7 @@ struct RngTask {
         u3 = e;
     }
     __device__ __forceinline__ double next() {
-        if (idx == (u32)RB_TASK) {  // only after a binomial redraw
+        if (__builtin_expect(idx == (u32)RB_TASK, 0)) {  // only after a binomial redraw
             pos = mt_wrap(pos + 2 * idx);
             ahead -= 2 * idx;
             used += idx;
@@ -779,7 +779,7 @@ struct Buffer {
     Rec head_rec;
     template <class DEV>
     __device__ __forceinline__ void push(const DEV& d, int64_t lane, u32 n_off, Rec rec) {
-        if (len >= (u32)d.capB) {
+        if (__builtin_expect(len >= (u32)d.capB, 0)) {
             flag(d, EC_ST_BUFFER_OVERFLOW);
             return;
         }
@@ -1750,7 +1750,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
             m.hop = newt.hop;
             double unused;
             m.nd = lut.deadline_ticks(0, 0, m.twt, m.ctt, m.bwt, &unused);
-            if (wq_len >= (u32)d.capW) {
+            if (__builtin_expect(wq_len >= (u32)d.capW, 0)) {
                 flag(d, EC_ST_WAIT_OVERFLOW);
             } else {
                 const u32 pos = (wq_h + wq_len) & wmask;
@@ -1762,7 +1762,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
                 const u32 da = wmeta_drop_at(pm);
                 wq_min = da < wq_min ? da : wq_min;
             }
-        } else if (slot < 0) {
+        } else if (__builtin_expect(slot < 0, 0)) {
             flag(d, EC_ST_BAD_ACTION);  // reference: ZeroDivisionError at edge_node.py:227
         } else {
             n_off++;
@@ -1775,7 +1775,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
             r.enq = c0;
             // receiving_queues[self.id] of the destination has this lane as its only producer
             const u32 ql = S.rqlen[slot * NT + dt_], qh = S.rqhead[slot * NT + dt_];
-            if (ql >= (u32)d.capR) {
+            if (__builtin_expect(ql >= (u32)d.capR, 0)) {
                 flag(d, EC_ST_RECV_OVERFLOW);
             } else {
                 if (ql == 0) {
@@ -1991,7 +1991,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
             EC_SUB(1);
 
             // the draws of this mini-slot: one per executing task, then one per non-empty receiving queue (q in all)
-            if (frng.idx + q > frng.staged && !f_final) {
+            if (__builtin_expect(frng.idx + q > frng.staged && !f_final, 0)) {
                 // the producer is still filling this window: it has been at it since the second barrier
                 u32 st;
                 while (!((st = __hip_atomic_load(&S.rc[RC_STAGED * NT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) &
@@ -2002,8 +2002,8 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
                 hot = S.hot[tid];
                 f_final = true;
             }
-            if (frng.idx + q > frng.staged) {
-                if (!f_synced) {
+            if (__builtin_expect(frng.idx + q > frng.staged, 0)) {
+                if (__builtin_expect(!f_synced, 0)) {
                     // the producer may still be regenerating this stream: wait for it (it never waits for us)
                     while (__hip_atomic_load(&S.rc[RC_DONE * NT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
                         __builtin_amdgcn_s_sleep(2);
@@ -2053,7 +2053,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
                 for (int s = 0; s < KMAX; s++) {
                     const bool act = (u32)s < n0;
                     bool fail = act && ae[s] > exA_thr;
-                    if (act && ae[s] == exA_thr)  // 2^-27 tie on the first word
+                    if (__builtin_expect(act && ae[s] == exA_thr, 0))  // 2^-27 tie on the first word
                         fail = frng.b_of(base + s) > (u32)(d.thr_exec_m[node] & 0x3ffffffull);
                     const bool done = act && !fail && c >= exf[s];
                     const bool succ = done && (exh[s] & EXH_SUCCESS);
@@ -2071,7 +2071,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
                         ct = done ? dadd(ct, exT[s]) : ct;
                         if (succ) {
                             u32 bin = hop;
-                            if (bin >= (u32)d.H) {
+                            if (__builtin_expect(bin >= (u32)d.H, 0)) {
                                 bin = d.H - 1;
                                 flag(d, EC_ST_HOP_OVERFLOW);
                             }
@@ -2104,7 +2104,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
                         rew = dadd(rew, d.rew_succ);
                         rew = dadd(rew, hop > 1 ? dmul(d.pen_hop, (double)(hop - 1)) : 0.0);
                         u32 bin = hop;
-                        if (bin >= (u32)d.H) {
+                        if (__builtin_expect(bin >= (u32)d.H, 0)) {
                             bin = d.H - 1;
                             flag(d, EC_ST_HOP_OVERFLOW);
                         }
@@ -2186,7 +2186,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
             for (int s = 0; s < DMAX; s++) {
                 const bool ne = rql[s] > 0;
                 bool failed = ne && ar[s] > lkA[s];
-                if (ne && ar[s] == lkA[s])  // 2^-27 tie on the first word
+                if (__builtin_expect(ne && ar[s] == lkA[s], 0))  // 2^-27 tie on the first word
                     failed = frng.b_of(ir[s]) > (u32)(d.thr_link_m[node * D + s] & 0x3ffffffull);
                 const bool arrived = ne && !failed && c >= rqa[s];
                 ev |= (failed || arrived) ? (1u << s) : 0u;
@@ -2222,7 +2222,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
                 for (int q = 0; q < DMAX; q++) cur = s == q ? rql[q] : cur;
                 const u32 ql = cur - 1;
                 u32 arr = NEVER;
-                if (ql > 0) {  // deeper than one: the next record lives in the global ring
+                if (__builtin_expect(ql > 0, 0)) {  // deeper than one: the next record lives in the global ring
                     const uint4* q = reinterpret_cast<const uint4*>(d.rq + ((size_t)s * d.capR + qh) * P + lane);
                     union {
                         Rec r;
@@ -2521,7 +2521,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
             S.rc[RC_FAHEAD * NT + tid] = ahead;
         }
         d.rng_cnt[P + lane] = cnt_f + 2ull * used;
-        if (ovf | lut.ovf) flag(d, EC_ST_TICK_OVERFLOW);
+        if (__builtin_expect((ovf | lut.ovf) != 0, 0)) flag(d, EC_ST_TICK_OVERFLOW);
     }
     EC_STAMP(6);
     EC_STAMP(7);
