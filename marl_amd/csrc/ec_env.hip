@@ -1602,7 +1602,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
     // producer, part 1: this step's task doubles and the failure window, straight from the words regenerated
     // ahead of the cursors during the previous step (per-lane regeneration only if that invariant is absent)
     u32 prod_tpos = 0;  // the task cursor at the start of this step (producer lanes)
-    if (R.valid) {
+    if (__builtin_expect(R.valid, 0)) {  // (out of line: the main wave, the step's critical path, falls through)
         const int ri = R.lidx;
         const size_t tl = (size_t)R.lane, fl = (size_t)P + (size_t)R.lane;
         // cursors: from global memory, or -- a carried step -- from where the consumer left them in LDS
@@ -1683,7 +1683,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
     EC_STAMP_P(11);
     __syncthreads();
     EC_STAMP(1);
-    if (EVX && has_producers && producer_wave && R.valid) {
+    if (__builtin_expect(EVX && has_producers && producer_wave && R.valid, 0)) {
         // Looping kernels: the rest of the failure window NOW, while the main lanes are in the offload phase and this wave
         // would wait at the next barrier -- all of it (the stream is regenerated a whole window ahead of the cursor; the
         // step's draw bound, known only behind that barrier, merely says how much of it can be used).  Part 2 below is
@@ -1804,7 +1804,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
 
     // producer, part 2 (concurrent with the mini-slots when it has a wave of its own): regenerate both streams
     // far enough ahead that the NEXT step finds its window and task doubles ready whatever this step consumes
-    if (producer_wave) {
+    if (__builtin_expect(producer_wave, 0)) {
         u32 tpos = 0, tah = 0, fpos = 0, fah = 0, want_f = 0;
         const int ri = R.lidx;
         if (R.valid) {
@@ -2340,7 +2340,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
     }
     __syncthreads();
     // the per-env sums are the producer lanes' job when they have a wave of their own (it is idle by now)
-    if (R.valid && R.node == 0) {
+    if (__builtin_expect(R.valid && R.node == 0, 0)) {
         const int ri = R.lidx;
         const u32 tick0 = has_producers ? d.tick[R.env] : c0;
         const u32 steps0 = has_producers ? d.total_steps[R.env] : steps_before;
@@ -2362,7 +2362,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
         if (terminated) terminated[R.env] = step_now >= (u32)d.T ? 1 : 0;  // :139-142
     }
 
-    if (has_producers && obs_direct && !last && R.valid && producer_wave) {
+    if (__builtin_expect(has_producers && obs_direct && !last && R.valid && producer_wave, 0)) {
         // Part 1 of the NEXT step, now: the cursors are final, the failure window is dead (phase E in its direct form
         // does not borrow it) and the main lanes have taken this step's task doubles, so the memory round trip of the
         // next early window runs under phases D and E instead of ahead of the next step's first barrier.  The task
@@ -2427,14 +2427,14 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
             for (u32 u = 0; u < 4; u++)
                 if (j0 + u < wq_len) wait_sum = dadd(wait_sum, et[u]);  // get_waiting_time, edge_node.py:99-104
         }
-        if (last && wq_dirty) {
+        if (__builtin_expect(last && wq_dirty, 0)) {
             for (u32 j = 0; j < wq_len; j++) {
                 const u32 pos = (wq_h + j) & wmask;
                 d.wqm[(size_t)j * P + lane] = S.wqm[pos * NT + tid];
                 d.wqe[(size_t)j * P + lane] = S.wqe[pos * NT + tid];
             }
         }
-        if (last) {
+        if (__builtin_expect(last, 0)) {
             d.has_new[lane] = has_new;
             if (has_new) store_rec(d.newt + lane, nnew);
             d.n_off[lane] = n_off;
@@ -2504,7 +2504,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
         }
         u32 pos, ahead, used;
         trng.close(pos, ahead, used);
-        if (last) {
+        if (__builtin_expect(last, 0)) {
             d.rng_pos[lane] = pos;
             d.rng_ahead[lane] = ahead;
         } else {  // the producer lane of the next step reads them here (after the step's closing barrier)
@@ -2513,7 +2513,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
         }
         d.rng_cnt[lane] = cnt_t + 2ull * used;
         frng.close(pos, ahead, used);
-        if (last) {
+        if (__builtin_expect(last, 0)) {
             d.rng_pos[P + lane] = pos;
             d.rng_ahead[P + lane] = ahead;
         } else {
@@ -2529,7 +2529,7 @@ __device__ __forceinline__ void step_body(const DEV& d, const int64_t* __restric
 #ifdef ABL_NO_OBS
     if (false) {
 #else
-    if (obs_direct) {
+    if (__builtin_expect(obs_direct, 1)) {  // (the staged form below goes out of line)
 #endif
         // edge_node.py:109-136,179-197 per lane (see observe_block for the staged form of the same arithmetic)
         const bool full = L.valid && (double)wq_len >= o_qthr;  // :186-188
