@@ -2746,8 +2746,8 @@ __device__ __forceinline__ int rollout_policy_rows(const float* __restrict__ st,
         if (A <= 16) return polinl::policy_rows<2, G>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane, pst);
 #endif
     if constexpr (TO3 == 1)
-        return A <= 16 ? polinl::policy_rows<2, G>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane)
-                       : polinl::policy_rows<4, G>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane);
+        return __builtin_expect(A <= 16, 1) ? polinl::policy_rows<2, G>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane)
+                                            : polinl::policy_rows<4, G>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane);
     else
         return A <= 48 ? polinl::policy_rows<6, G, 2>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane)
                        : polinl::policy_rows<8, G, 2>(st, s_b23, obs, avail, uniforms, actions, row0, cnt, n_agents, A, lane);
@@ -2809,7 +2809,7 @@ __global__ void __launch_bounds__(256, 2) k_rollout_mlp(const EcDev* d_mem, MlpR
                 const int r0 = wave * per;
                 int cnt = nrows - r0 < per ? nrows - r0 : per;
                 if (split && cnt > 32) cnt = 32;
-                if (cnt > 32) {
+                if (__builtin_expect(cnt > 32, 0)) {  // (geometries without producer waves; out of line)
                     pick = rollout_policy_rows<TO3, 2>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane);
                 } else if (cnt > 0) {
                     pick = rollout_policy_rows<TO3, 1>(m.staged, s_b23, ob, av, un, act, row_base + r0, cnt, d.N, d.A, lane POL_PST);
