@@ -476,7 +476,8 @@ int ec_linear_fwd(const float* x, const float* w, const float* b, int64_t rows, 
                   void* stream);
 /* ec_linear_fwd that also leaves the batch statistics of y for a BatchNorm that follows (gail_network.py:97-125: fc -> bn):
  * partials [n_partials <= 1024][2][c_out] <- per-block column sums of (y - pivot) and (y - pivot)^2, the input of
- * ec_bn_finalize with x_row0 = pivot; pivot [c_out] = a row of y (the caller's one-row call).  Saves the statistics pass. */
+ * ec_bn_finalize with x_row0 = pivot; pivot [c_out] = a row of y (the caller's one-row call).  Saves the statistics pass.
+ * y = NULL: the statistics only, nothing of y written (for a layer whose output ec_linear2_fwd_bn recomputes). */
 int ec_linear_fwd_stats(const float* x, const float* w, const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y,
                         const float* pivot, int32_t n_partials, float* partials, void* stream);
 /* The same with the previous layer's BatchNorm -> ReLU -> Dropout tail applied on the way in:
@@ -488,6 +489,24 @@ int ec_linear_fwd_stats(const float* x, const float* w, const float* b, int64_t 
 int ec_linear_fwd_bn(const float* x, const float* scale, const float* shift, uint64_t seed, float p, const float* w,
                      const float* b, int64_t rows, int32_t k_in, int32_t c_out, float* y, int32_t n_partials, float* partials,
                      void* stream);
+/* Layers 1 and 2 of the GAIL discriminator (gail_network.py:97-125: fc1 -> bn1 -> relu -> dropout1 -> fc2) in one kernel,
+ * for the reward pass (gail_agent.py:165-170: training mode under no_grad, nothing kept for a backward):
+ *   y [rows, c_out = 64] = (relu((x W1^T + b1) * scale + shift) * keep / (1 - p)) W2^T + b2
+ * x [rows, k_in <= 96], w1 [c_mid = 128, k_in], w2 [64, 128], b1 / b2 or NULL; scale, shift [128] of bn1 from a
+ * statistics-only pass (ec_linear_fwd_stats with y = NULL, ec_bn_finalize); keep as in ec_linear_fwd_bn (element index
+ * row * 128 + col).  Layer 1's [rows, 128] output -- two thirds of the two layers' memory traffic -- is neither written
+ * nor read back.  y equals ec_linear_fwd followed by ec_linear_fwd_bn bit for bit; partials as in ec_linear_fwd_bn
+ * ([n_partials <= 1024][2][64] about b2).  Other widths: EC_EINVAL (the caller takes the layer-by-layer kernels). */
+int ec_linear2_fwd_bn(const float* x, const float* w1, const float* b1, const float* scale, const float* shift, uint64_t seed,
+                      float p, const float* w2, const float* b2, int64_t rows, int32_t k_in, int32_t c_mid, int32_t c_out,
+                      float* y, int32_t n_partials, float* partials, void* stream);
+
+/* First and second moments of the rows of x [rows, k_in <= 96] about its first row, the row index as the MFMA's K
+ * dimension: partials [n_partials <= 4096][KP * KP + KP], KP = 32 ceil(k_in / 32) <- per block, sum over its rows of d d^T
+ * (KP x KP row-major, zero beyond k_in), then sum of d, with d = x[row] - x[0].  The batch statistics of fc1's output for
+ * bn1 (gail_network.py:97-125) follow from them without computing that output: sum(y - y0) = W sum(d) and
+ * sum((y - y0)^2)[o] = w_o^T (sum d d^T) w_o.  Replaces the statistics pass over fc1(x) in the reward pass. */
+int ec_row_moments(const float* x, int64_t rows, int32_t k_in, int32_t n_partials, float* partials, void* stream);
 
 /* The GAIL discriminator's input rows (gail_agent.py:131-141, gail_network.py:127-131: obs with the agent's one-hot id,
  * concatenated with the one-hot action): out [rows, obs_dim + n_agents + n_actions] fp32 from obs [rows, obs_dim] fp32 and

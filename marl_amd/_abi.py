@@ -177,6 +177,8 @@ def lib():
     L.ec_linear_fwd_stats.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, i32, vp, vp]
     L.ec_disc_rows.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
     L.ec_linear_fwd_bn.argtypes = [vp, vp, vp, u64, f32, vp, vp, i64, i32, i32, vp, i32, vp, vp]
+    L.ec_row_moments.argtypes = [vp, i64, i32, i32, vp, vp]
+    L.ec_linear2_fwd_bn.argtypes = [vp, vp, vp, vp, vp, u64, f32, vp, vp, i64, i32, i32, i32, vp, i32, vp, vp]
     L.ec_bn_finalize.argtypes = [vp, i32, vp, i64, i32, vp, vp, f32, f32] + [vp] * 9
     L.ec_bn_bwd_coeffs.argtypes = [vp, i32, vp, vp, vp, i64, i32] + [vp] * 6
     L.ec_bn_relu_dropout_fwd.argtypes = [vp, vp, vp, vp, u64, f32, i64, i32, vp, vp]
@@ -192,7 +194,7 @@ def lib():
                "ec_policy_forward", "ec_gail_reward", "ec_diffusion_reward", "ec_diffusion_grad", "ec_expert_policy",
                "ec_ppo_actor_grad", "ec_ppo_critic_grad", "ec_ppo_actor_grad_ex", "ec_ppo_critic_grad_ex", "ec_gail_disc_grad", "ec_store_transition", "ec_bn_relu_dropout_fwd", "ec_bn_relu_dropout_bwd_sums", "ec_bn_relu_dropout_bwd_dx", "ec_expert_mix", "ec_store_episode", "ec_store_episode_static",
                "ec_step_random_policy", "ec_rollout_random_policy", "ec_rollout_mlp_policy",
-               "ec_rollout_mlp_expert_policy", "ec_expert_append_episode", "ec_adam_clip_step", "ec_bn_col_stats", "ec_diffusion_grad_bce", "ec_linear_wgrad", "ec_bn_finalize", "ec_bn_bwd_coeffs", "ec_linear_fwd", "ec_linear_fwd_bn", "ec_disc_rows", "ec_linear_fwd_stats",
+               "ec_rollout_mlp_expert_policy", "ec_expert_append_episode", "ec_adam_clip_step", "ec_bn_col_stats", "ec_diffusion_grad_bce", "ec_linear_wgrad", "ec_bn_finalize", "ec_bn_bwd_coeffs", "ec_linear_fwd", "ec_linear_fwd_bn", "ec_linear2_fwd_bn", "ec_row_moments", "ec_disc_rows", "ec_linear_fwd_stats",
                "ec_diffusion_reward_from_loss"):
         getattr(L, fn).restype = C.c_int
     L.ec_last_error.restype = C.c_char_p

@@ -190,7 +190,7 @@ def _draw_seed():
     return int(th.empty((), dtype=th.int64).random_())
 
 
-def _bn_batch_stats(x, weight, bias, eps, running, partials=None, pivot=None, sync=False):
+def _bn_batch_stats(x, weight, bias, eps, running, partials=None, pivot=None, sync=False, shape=None):
     """mean, var, invstd, scale, shift [C] of a training-mode BatchNorm over x [rows, C] (fp32, on the device), and the
     module's running statistics updated: one streaming pass (ec_bn_col_stats; torch.var_mean's column reduction runs at
     a third of the HBM rate) leaving per-block partial sums about the pivot row x[0], then ec_bn_finalize, which adds
@@ -201,27 +201,29 @@ def _bn_batch_stats(x, weight, bias, eps, running, partials=None, pivot=None, sy
     sums of (x - pivot) and (x - pivot)^2); only ec_bn_finalize runs.
     sync (data parallel): the statistics are the whole job's -- every rank turns its partial sums into (n, mean, sum of
     squared deviations) in float64, the ranks' moments are merged (Chan's formula, two small all-reduces: the pivots
-    differ per rank, so the partial sums themselves cannot be added), and the per-column tail runs as torch ops."""
+    differ per rank, so the partial sums themselves cannot be added), and the per-column tail runs as torch ops.
+    x = None with shape = (rows, C): a tensor that was never written (its statistics came with `partials`)."""
     import ctypes as C
 
     from marl_amd import _abi
-    rows, Cc = x.shape
-    stream = C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)
+    rows, Cc = x.shape if x is not None else shape
+    dev = x.device if x is not None else partials.device
+    stream = C.c_void_p(th.cuda.current_stream(dev).cuda_stream)
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
     have = partials is not None
     if have:
         n_part = partials.shape[0]
     else:
         n_part = int(min(_BnReluDropHipFn.N_PARTIALS, max(1, rows // 64)))
-        partials = th.empty(n_part, 2, Cc, dtype=th.float32, device=x.device)
+        partials = th.empty(n_part, 2, Cc, dtype=th.float32, device=dev)
         pivot = x   # (its first row)
-    cols = th.empty(5, Cc, dtype=th.float32, device=x.device)
+    cols = th.empty(5, Cc, dtype=th.float32, device=dev)
     mean, var, invstd, scale, shift = cols.unbind(0)
     rm, rv, nbt, momentum = running if running is not None else (None, None, None, 0.0)
     if nbt is not None:
         nbt.data += 1  # (before the launch: momentum=None weighs this batch 1 / count)
     if sync and dist_on():
-        with th.cuda.device(x.device):
+        with th.cuda.device(dev):
             if not have:
                 _abi.check(_abi.lib().ec_bn_col_stats(ptr(x), rows, Cc, n_part, ptr(partials), stream), "ec_bn_col_stats")
         with th.no_grad():
@@ -229,7 +231,7 @@ def _bn_batch_stats(x, weight, bias, eps, running, partials=None, pivot=None, sy
             k = pivot.reshape(-1, Cc)[0].double() if pivot.dim() > 1 else pivot.double()
             m_r = k + s[0] / rows
             m2_r = s[1] - s[0] * s[0] / rows
-            stat = th.cat([th.full((1,), float(rows), dtype=th.float64, device=x.device), m_r * rows])
+            stat = th.cat([th.full((1,), float(rows), dtype=th.float64, device=dev), m_r * rows])
             all_reduce_sum_(stat)
             n = stat[0]
             g_mean = stat[1:] / n
@@ -246,7 +248,7 @@ def _bn_batch_stats(x, weight, bias, eps, running, partials=None, pivot=None, sy
                 rm.data.mul_(1 - mo).add_(mean, alpha=mo)
                 rv.data.mul_(1 - mo).add_((g_var * (n / (n - 1).clamp(min=1))).float(), alpha=mo)
         return mean, var, invstd, scale, shift
-    with th.cuda.device(x.device):
+    with th.cuda.device(dev):
         if not have:
             _abi.check(_abi.lib().ec_bn_col_stats(ptr(x), rows, Cc, n_part, ptr(partials), stream), "ec_bn_col_stats")
         _abi.check(_abi.lib().ec_bn_finalize(ptr(partials), n_part, ptr(pivot), rows, Cc, ptr(weight), ptr(bias), C.c_float(eps),
@@ -409,6 +411,8 @@ class Discriminator(nn.Module):
                 nn.init.xavier_uniform_(m.weight)
                 nn.init.constant_(m.bias, 0)
 
+    FUSE_FIRST_TWO = True   # the no-grad pass takes layers 1 and 2 in one kernel where ec_linear2_fwd_bn has the shape
+
     def forward(self, obs, actions):
         lead = obs.shape[:-1]
         x = self.forward_rows(self.rows(obs, actions))
@@ -438,11 +442,24 @@ class Discriminator(nn.Module):
         statistics pass over the Linear's output, then BatchNorm -> ReLU -> Dropout applied inside the NEXT Linear's
         kernel, with the draws (one seed per layer, in layer order) the two-step path would make"""
         partials = pivot = None
-        if linear_device.fwd_ok(x, self.fc1.weight):   # the first layer's statistics from the kernel that computes it
+        first = 1
+        if self.FUSE_FIRST_TWO and linear_device.fwd2_bn_ok(x, self.fc1.weight, self.fc2.weight) and self.fc2.bias is not None:
+            # layers 1 and 2 in one kernel (ec_linear2_fwd_bn): bn1's statistics from the moments of the input rows
+            # (ec_row_moments), then layer 1 in registers -> tail -> layer 2; the 128-wide tensor is never written
+            bn, drop = self.bn1, self.dropout1
+            running = (bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum) if bn.track_running_stats else None
+            partials, pivot = linear_device.fwd_stats_from_moments(x, self.fc1.weight, self.fc1.bias)
+            _, _, _, scale, shift = _bn_batch_stats(None, bn.weight, bn.bias, bn.eps, running, partials, pivot, sync=sync,
+                                                    shape=(x.shape[0], self.fc1.weight.shape[0]))
+            x, partials = linear_device.fwd2_bn(x, self.fc1.weight, self.fc1.bias, scale, shift, _draw_seed(), float(drop.p),
+                                                self.fc2.weight, self.fc2.bias, want_stats=True)
+            pivot = self.fc2.bias.detach()
+            first = 2
+        elif linear_device.fwd_ok(x, self.fc1.weight):   # the first layer's statistics from the kernel that computes it
             x, partials, pivot = linear_device.fwd(x, self.fc1.weight, self.fc1.bias, want_stats=True)
         else:
             x = self.fc1(x)
-        for i in (1, 2, 3):
+        for i in range(first, 4):
             bn, drop, nxt = getattr(self, "bn%d" % i), getattr(self, "dropout%d" % i), getattr(self, "fc%d" % (i + 1))
             running = None
             if bn.track_running_stats:

@@ -62,6 +62,79 @@ def fwd(x, w, b=None, want_stats=False):
     return y
 
 
+def fwd_stats_only(x, w, b):
+    """(partials [n, 2, c_out], pivot [c_out]) of y = x @ w.t() + b WITHOUT y (ec_linear_fwd_stats with y = NULL): the same
+    partials and pivot (y's first row) `fwd(..., want_stats=True)` leaves, for a layer whose output a later kernel
+    recomputes (fwd2_bn)"""
+    x, w = x.contiguous(), w.contiguous()
+    rows, k_in = x.shape
+    c_out = w.shape[0]
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    b_ = b.contiguous() if b is not None else None
+    pivot = fwd(x[:1], w, b_).reshape(c_out)
+    n_part = int(min(1024, max(1, (rows + 127) // 128)))
+    partials = th.empty(n_part, 2, c_out, dtype=th.float32, device=x.device)
+    with th.cuda.device(x.device):
+        _abi.check(_abi.lib().ec_linear_fwd_stats(ptr(x), ptr(w), ptr(b_), rows, k_in, c_out, ptr(None), ptr(pivot), n_part,
+                                                  ptr(partials), C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)),
+                   "ec_linear_fwd_stats")
+    return partials, pivot
+
+
+def fwd_stats_from_moments(x, w, b):
+    """(partials [1, 2, c_out], pivot [c_out]) for ec_bn_finalize over y = x @ w.t() + b, from the moments of x's rows
+    (ec_row_moments) instead of a pass that computes y: with d = x[row] - x[0], sum(y - y0) = W sum(d) and
+    sum((y - y0)^2)[o] = w_o^T (sum d d^T) w_o; the block sums are added and the two small products taken in float64"""
+    x, w = x.contiguous(), w.contiguous()
+    rows, k_in = x.shape
+    c_out = w.shape[0]
+    kp = 32 * ((k_in + 31) // 32)
+    n_part = int(min(1024, max(1, (rows + 127) // 128)))
+    part = th.empty(n_part, kp * kp + kp, dtype=th.float32, device=x.device)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    with th.cuda.device(x.device):
+        _abi.check(_abi.lib().ec_row_moments(ptr(x), rows, k_in, n_part, ptr(part),
+                                             C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)), "ec_row_moments")
+    tot = part.sum(0, dtype=th.float64)
+    m2 = tot[:kp * kp].view(kp, kp)[:k_in, :k_in]
+    wd = w.double()
+    partials = th.stack([wd @ tot[kp * kp:kp * kp + k_in], ((wd @ m2) * wd).sum(1)]).float().reshape(1, 2, c_out)
+    pivot = fwd(x[:1], w, b.contiguous() if b is not None else None).reshape(c_out)
+    return partials, pivot
+
+
+def fwd2_bn_ok(x, w1, w2):
+    """shapes for which ec_linear2_fwd_bn wins: [rows, <= 32] -> 128 -> 64 (the GAIL discriminator's first two layers at
+    hidden_dim 64 and 10 nodes).  The kernel takes up to 96 inputs, but beyond one 32-input tile it spills and loses to
+    the layer-by-layer kernels (8.2 M rows x 90 inputs, the 40-node shape: 8.3 ms against 5.5; tools/prof_reward_pass.sh)"""
+    return (x.is_cuda and w1.is_cuda and w2.is_cuda and x.dtype == w1.dtype == w2.dtype == th.float32 and x.dim() == 2
+            and w1.dim() == 2 and w2.dim() == 2 and x.shape[1] == w1.shape[1] and 1 <= x.shape[1] <= 32
+            and tuple(w1.shape[:1]) == (128,) and tuple(w2.shape) == (64, 128) and not th.is_grad_enabled())
+
+
+def fwd2_bn(x, w1, b1, scale, shift, seed, p, w2, b2, want_stats=False):
+    """dropout(relu((x @ w1.t() + b1) * scale + shift), p) @ w2.t() + b2 in one kernel (ec_linear2_fwd_bn): layer 1's output
+    stays in registers.  Bit-equal to fwd_bn(fwd(x, w1, b1), scale, shift, seed, p, w2, b2); want_stats as in fwd_bn."""
+    x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
+    rows, k_in = x.shape
+    c_mid, c_out = w1.shape[0], w2.shape[0]
+    y = th.empty(rows, c_out, dtype=th.float32, device=x.device)
+    b1 = b1.contiguous() if b1 is not None else None
+    b2 = b2.contiguous() if b2 is not None else None
+    partials, n_part = None, 0
+    if want_stats:
+        assert b2 is not None
+        n_part = int(min(1024, max(1, (rows + 127) // 128)))
+        partials = th.empty(n_part, 2, c_out, dtype=th.float32, device=x.device)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    with th.cuda.device(x.device):
+        _abi.check(_abi.lib().ec_linear2_fwd_bn(ptr(x), ptr(w1), ptr(b1), ptr(scale.contiguous()), ptr(shift.contiguous()),
+                                                C.c_uint64(seed), C.c_float(p), ptr(w2), ptr(b2), rows, k_in, c_mid, c_out, ptr(y),
+                                                n_part, ptr(partials), C.c_void_p(th.cuda.current_stream(x.device).cuda_stream)),
+                   "ec_linear2_fwd_bn")
+    return (y, partials) if want_stats else y
+
+
 def fwd_bn_ok(x, w):
     """shapes ec_linear_fwd_bn takes (any k_in <= 128: against a separate tail kernel plus a GEMM it wins at 128 too)"""
     return (x.is_cuda and w.is_cuda and x.dtype == th.float32 and w.dtype == th.float32 and x.dim() == 2 and w.dim() == 2

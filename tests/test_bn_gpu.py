@@ -237,6 +237,99 @@ def test_linear_fwd_bn_equals_tail_then_linear(rows, k_in, c_out, p):
     assert lib.ec_linear_fwd_bn(vp(x), C.c_void_p(0), vp(shift), C.c_uint64(1), C.c_float(0.1), vp(w), vp(b), rows, k_in, c_out, vp(x), 0, C.c_void_p(0), stream) != 0
 
 
+@pytest.mark.parametrize("rows,k_in,p", [(70001, 30, 0.3), (4097, 50, 0.3), (33, 90, 0.0), (2, 9, 0.5), (100003, 64, 0.25),
+                                         (1, 30, 0.3), (262144 + 5, 96, 0.3)])
+def test_linear2_fwd_bn_equals_two_kernels(rows, k_in, p):
+    """ec_linear2_fwd_bn (layers 1 and 2 of the GAIL discriminator in one kernel, layer 1's 128-wide output in registers)
+    against the two kernels it replaces -- ec_linear_fwd, then ec_linear_fwd_bn -- for the same seed: y bit for bit (same
+    products in the same order, the same tail arithmetic and keep_draw); its statistics epilogue against float64; and
+    the statistics-only form of ec_linear_fwd_stats (y = NULL) leaves the partials of the form that writes y."""
+    import ctypes as C
+    from marl_amd import _abi
+    from marl_amd.utils import linear_device
+    gen = th.Generator().manual_seed(rows + k_in)
+    x = th.randn(rows, k_in, generator=gen).cuda()
+    w1, b1 = (th.randn(128, k_in, generator=gen) * 0.3).cuda(), th.randn(128, generator=gen).cuda()
+    w2, b2 = (th.randn(64, 128, generator=gen) * 0.2).cuda(), th.randn(64, generator=gen).cuda()
+    scale, shift = (th.rand(128, generator=gen) + 0.5).cuda(), (th.randn(128, generator=gen) * 0.5).cuda()
+    seed = 0x0fedcba987654321 + rows
+    with th.no_grad():
+        assert linear_device.fwd2_bn_ok(x, w1, w2) == (k_in <= 32)   # (wider rows: the kernel is correct but not the product's choice)
+        for bias1, bias2 in ((b1, b2), (None, None)):
+            y1 = linear_device.fwd(x, w1, bias1)
+            want = linear_device.fwd_bn(y1, scale, shift, seed, p, w2, bias2)
+            got = linear_device.fwd2_bn(x, w1, bias1, scale, shift, seed, p, w2, bias2)
+            assert th.equal(got, want)
+        y_stats, partials = linear_device.fwd2_bn(x, w1, b1, scale, shift, seed, p, w2, b2, want_stats=True)
+        assert th.equal(y_stats, got if bias2 is not None else linear_device.fwd2_bn(x, w1, b1, scale, shift, seed, p, w2, b2))
+        assert partials.shape[1:] == (2, 64)
+        d = y_stats.double() - b2.double()
+        got_s = partials.double().sum(0)
+        for which, want_s in ((0, d.sum(0)), (1, (d * d).sum(0))):
+            scale_ = (d.abs() if which == 0 else d * d).sum(0) + 1e-30
+            assert float(((got_s[which] - want_s).abs() / scale_).max()) < 2e-6, which
+        # the statistics of layer 1 without writing it
+        if k_in <= 64:
+            _, part_y, piv_y = linear_device.fwd(x, w1, b1, want_stats=True)
+            part_n, piv_n = linear_device.fwd_stats_only(x, w1, b1)
+            assert th.equal(part_y, part_n) and th.equal(piv_y, piv_n)
+    lib = _abi.lib()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
+    y = th.empty(rows, 64, device="cuda")
+    args = lambda k=k_in, cm=128, co=64, pp=0.1: (vp(x), vp(w1), vp(b1), vp(scale), vp(shift), C.c_uint64(1), C.c_float(pp), vp(w2),
+                                                   vp(b2), rows, k, cm, co, vp(y), 0, C.c_void_p(0), stream)
+    assert lib.ec_linear2_fwd_bn(*args()) == 0
+    assert lib.ec_linear2_fwd_bn(*args(k=97)) != 0
+    assert lib.ec_linear2_fwd_bn(*args(cm=64)) != 0
+    assert lib.ec_linear2_fwd_bn(*args(co=32)) != 0
+    assert lib.ec_linear2_fwd_bn(*args(pp=1.0)) != 0
+
+
+@pytest.mark.parametrize("rows,k_in", [(1, 30), (33, 30), (100003, 30), (70001, 50), (5000, 9), (40000, 90), (8192, 32),
+                                        (3000, 96), (262144 + 7, 64)])
+def test_row_moments_give_layer_statistics(rows, k_in):
+    """ec_row_moments (sums of d and d d^T over the rows, d = x[row] - x[0], the row index as the MFMA's K dimension)
+    against float64, with columns far from zero mean and one-hot columns as the discriminator's rows have them; and the
+    statistics of a Linear layer's output derived from them (linear_device.fwd_stats_from_moments) against the column
+    sums of the layer's actual output in float64."""
+    import ctypes as C
+    from marl_amd import _abi
+    from marl_amd.utils import linear_device
+    gen = th.Generator().manual_seed(rows * 7 + k_in)
+    x = th.randn(rows, k_in, generator=gen) * th.linspace(0.2, 3.0, k_in) + th.linspace(-5.0, 20.0, k_in)
+    hot = th.randint(0, max(1, k_in // 3), (rows,), generator=gen)
+    x[:, : max(1, k_in // 3)] = th.nn.functional.one_hot(hot, max(1, k_in // 3)).float()
+    x = x.cuda()
+    w, b = (th.randn(128, k_in, generator=gen) * 0.3).cuda(), th.randn(128, generator=gen).cuda()
+    kp = 32 * ((k_in + 31) // 32)
+    n_part = 64
+    part = th.full((n_part, kp * kp + kp), float("nan"), device="cuda")
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
+    lib = _abi.lib()
+    assert lib.ec_row_moments(vp(x), rows, k_in, n_part, vp(part), stream) == 0
+    tot = part.double().sum(0)
+    d = x.double() - x[0].double()
+    m2, s1 = tot[:kp * kp].view(kp, kp), tot[kp * kp:]
+    want_m2 = d.t() @ d
+    assert float((m2[:k_in, :k_in] - want_m2).abs().max()) <= 2e-6 * float((d.abs().t() @ d.abs()).max() + 1e-30) + 1e-30
+    assert float((s1[:k_in] - d.sum(0)).abs().max()) <= 2e-6 * float(d.abs().sum(0).max() + 1e-30) + 1e-30
+    assert float(m2[k_in:].abs().sum() + m2[:, k_in:].abs().sum() + s1[k_in:].abs().sum()) == 0.0
+    with th.no_grad():
+        partials, pivot = linear_device.fwd_stats_from_moments(x, w, b)
+        y = x.double() @ w.double().t() + b.double()
+        assert partials.shape == (1, 2, 128) and th.equal(pivot, linear_device.fwd(x[:1], w, b).reshape(128))
+        dy = y - pivot.double()
+        if rows > 1:
+            for which, want_s in ((0, dy.sum(0)), (1, (dy * dy).sum(0))):
+                scale_ = (dy.abs() if which == 0 else dy * dy).sum(0) + 1e-30
+                assert float(((partials[0, which].double() - want_s).abs() / scale_).max()) < 1e-5, which
+    assert lib.ec_row_moments(vp(x), rows, 97, n_part, vp(part), stream) != 0
+    assert lib.ec_row_moments(vp(x), 0, k_in, n_part, vp(part), stream) != 0
+    assert lib.ec_row_moments(vp(x), rows, k_in, 0, vp(part), stream) != 0
+
+
 @pytest.mark.parametrize("rows,n_agents,n_actions", [(50000, 10, 11), (20000, 40, 41)])
 def test_discriminator_no_grad_pass_fused_tails(rows, n_agents, n_actions, monkeypatch):
     """Discriminator.forward_rows under no_grad in training mode (GAIL's reward pass, gail_agent.py:165-167) folds every
@@ -268,6 +361,25 @@ def test_discriminator_no_grad_pass_fused_tails(rows, n_agents, n_actions, monke
     for (na, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
         assert th.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-6), na
     assert int(a.bn1.num_batches_tracked) == 1
+    # layers 1 and 2 in one kernel (ec_linear2_fwd_bn, the default above) against one kernel per layer: the same draws,
+    # bn1's statistics from the moments of the input rows, bn2's from a differently ordered sum
+    monkeypatch.undo()
+    c = gn.Discriminator(args).cuda()
+    c.load_state_dict({k: v for k, v in a.state_dict().items()})
+    with th.no_grad():
+        for m in c.modules():
+            if isinstance(m, th.nn.BatchNorm1d):
+                m.reset_running_stats()
+        d = copy.deepcopy(c)
+        monkeypatch.setattr(gn.Discriminator, "FUSE_FIRST_TWO", False)
+        th.manual_seed(11)
+        yc = c.forward_rows(x)
+        monkeypatch.setattr(gn.Discriminator, "FUSE_FIRST_TWO", True)
+        th.manual_seed(11)
+        yd = d.forward_rows(x)
+    assert float((yc - yd).abs().max()) <= 2e-5 * float(yc.abs().max() + 1)
+    for (na, ba), (_, bb) in zip(c.named_buffers(), d.named_buffers()):
+        assert th.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-6), na
     # with grad enabled, or with a test's mask hook in place, the layer-by-layer path runs
     monkeypatch.undo()
     assert not a._fused_tails_ok(x.requires_grad_(True)) or not th.is_grad_enabled()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The GAIL reward pass (Discriminator.forward_rows under no_grad, training mode) three ways on one box: layer by layer,
-tails folded into the next layer (ec_linear_fwd_bn), and with the next BatchNorm's statistics from the same kernel."""
+"""The GAIL reward pass (Discriminator.forward_rows under no_grad, training mode) four ways on one box: layer by layer,
+tails folded into the next layer (ec_linear_fwd_bn), with the next BatchNorm's statistics from the same kernel, and with
+layers 1 and 2 in one kernel (ec_linear2_fwd_bn, the product's path)."""
 import os
 import sys
 from types import SimpleNamespace
@@ -33,12 +34,14 @@ def timed(fn, reps=10):
 
 
 with th.no_grad():
+    t_two = timed(lambda: disc.forward_rows(x))
+    gn.Discriminator.FUSE_FIRST_TWO = False
     t_full = timed(lambda: disc.forward_rows(x))
     real = linear_device.fwd_bn
     linear_device.fwd_bn = lambda *a, want_stats=False, **k: real(*a, **k)
     orig = gn.Discriminator._forward_rows_fused_tails
 
-    def no_stats(self, x_):
+    def no_stats(self, x_, sync=False):
         x_ = self.fc1(x_)
         for i in (1, 2, 3):
             bn, drop, nxt = getattr(self, "bn%d" % i), getattr(self, "dropout%d" % i), getattr(self, "fc%d" % (i + 1))
@@ -52,5 +55,5 @@ with th.no_grad():
     linear_device.fwd_bn = real
     gn.Discriminator._fused_tails_ok = lambda self, x_: False
     t_layers = timed(lambda: disc.forward_rows(x))
-print("rows %d, %d nodes: layer by layer %.2f ms, tails folded %.2f ms, + statistics from the same kernel %.2f ms" % (
-    rows, nodes, t_layers, t_tails, t_full))
+print("rows %d, %d nodes: layer by layer %.2f ms, tails folded %.2f ms, + statistics from the same kernel %.2f ms, "
+      "layers 1 and 2 in one kernel %.2f ms" % (rows, nodes, t_layers, t_tails, t_full, t_two))
