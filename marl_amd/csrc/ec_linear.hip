@@ -35,7 +35,11 @@ struct LinArgs {
 
 // (the keep flags are ec_bn.hip's keep_draw(seed, row * K + col), restated in the kernel with the per-row work hoisted: the
 // two must stay the same function -- tests compare the fused layer with the two-step one bit for bit)
-template <int TO, int TI, bool BN, bool ST>   // ST: the plain layer with the statistics epilogue (BN takes it at run time)
+// STG (K = 32 TI exactly, rows 16-byte aligned): the wave's 32 x K tile comes in as whole 1 KB runs -- lane l fetches the
+// tile's 16-byte pieces l, l + 64, .. -- and is handed to the row-per-lane order through a padded LDS tile; the next tile's
+// pieces are requested before this tile's MFMAs.  (Row-per-lane reads fetch 16 bytes of each of 32 rows per instruction:
+// 32 lines touched for 1 KB, and the 64 -> 32 and 32 -> 1 layers ran at 3.0 / 2.1 TB/s.)
+template <int TO, int TI, bool BN, bool ST, bool STG = false>   // ST: the plain layer with the statistics epilogue (BN takes it at run time)
 __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
     extern __shared__ __align__(16) float lds[];
     float* s_f = lds;                      // fragments: 16 TI steps x TO tiles x 64 lanes
@@ -43,6 +47,8 @@ __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
     float* s_sc = s_b + 32 * TO;           // BN: [32 TI] scale, [32 TI] shift
     float* s_sh = s_sc + 32 * TI;
     float* s_pv = s_sh + 32 * TI;          // [32 TO] pivot of the statistics
+    constexpr int KS = 32 * TI + 4;        // STG: row stride of a wave's staged tile (conflict-free 16-byte reads)
+    float* s_x = s_pv + 32 * TO + (threadIdx.x >> 6) * 32 * KS;
     const int K = p.K, C = p.C;
     stage_frag(s_f, p.w, K, 1, C, K, 16 * TI, TO, true);
     for (int i = threadIdx.x; i < 32 * TO; i += blockDim.x) {
@@ -63,7 +69,30 @@ __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
     float st1[TO], st2[TO];   // lane (out j, half): sums over the rows it held of output 32 to + j
 #pragma unroll
     for (int to = 0; to < TO; to++) st1[to] = st2[to] = 0.0f;
+    constexpr int NV = STG ? 4 * TI : 1;   // 16-byte pieces of a 32 x 32 TI tile per lane
+    float4 g[NV];
+    const int64_t total = p.rows * (int64_t)K;
+    const auto stage_load = [&](int64_t tile_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int64_t e = tile_ * 32 * K + 4 * (i * 64 + lane);
+            const bool in = e < total;   // (K a multiple of 4: a piece lies wholly inside or outside)
+            const float4 v = *reinterpret_cast<const float4*>(p.x + (in ? e : 0));
+            g[i] = make_float4(in ? v.x : 0.0f, in ? v.y : 0.0f, in ? v.z : 0.0f, in ? v.w : 0.0f);
+        }
+    };
+    if (STG) stage_load((int64_t)blockIdx.x * nw + wave);
     for (int64_t tile = (int64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += (int64_t)gridDim.x * nw) {
+        if (STG) {
+            wave_sync();   // (the previous tile's reads are done)
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const int idx = i * 64 + lane;
+                *reinterpret_cast<float4*>(s_x + (idx / (8 * TI)) * KS + 4 * (idx % (8 * TI))) = g[i];
+            }
+            wave_sync();
+            stage_load(tile + (int64_t)gridDim.x * nw);   // (past the last tile: zeros)
+        }
         const int64_t rowbase = tile * 32, row = rowbase + j;  // as the A operand, lane (j, half) is row j
         const bool ok = row < p.rows;
         const float* xr = p.x + (ok ? row : 0) * K;
@@ -94,7 +123,9 @@ __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int k0 = 32 * T + 8 * q + 4 * half;
-                if (vec) {
+                if (STG) {
+                    xa[q] = *reinterpret_cast<const float4*>(s_x + j * KS + k0);
+                } else if (vec) {
                     xa[q] = (ok && k0 < K) ? *reinterpret_cast<const float4*>(xr + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
                     xa[q].x = (ok && k0 + 0 < K) ? xr[k0 + 0] : 0.0f;
@@ -528,16 +559,20 @@ __global__ void __launch_bounds__(256) k_disc_rows(const float* __restrict__ obs
     }
 }
 
-template <int TO, int TI, bool BN, bool ST>
+template <int TO, int TI, bool BN, bool ST, bool STG = false>
 int launch_linear(const LinArgs& a, hipStream_t stream) {
-    const size_t lds = sizeof(float) * ((size_t)16 * TI * TO * 64 + 64 * TO + 64 * TI);
-    EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_fwd<TO, TI, BN, ST>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+    if constexpr (TI <= 2 && !STG) {   // the staged row load where it applies (header of k_linear_fwd)
+        if (a.K == 32 * TI && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0) return launch_linear<TO, TI, BN, ST, true>(a, stream);
+    }
+    const size_t lds = sizeof(float) * ((size_t)16 * TI * TO * 64 + 64 * TO + 64 * TI + (STG ? 4 * 32 * (32 * TI + 4) : 0));
+    EC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_fwd<TO, TI, BN, ST, STG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t tiles = (a.rows + 31) / 32;
     int64_t blocks = (tiles + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    const int64_t cap = STG ? 2048 : 1024;   // (staged: one tile in flight per wave, so more waves)
+    if (blocks > cap) blocks = cap;
     if (a.partials) blocks = a.n_partials;   // one partial per block: the caller sized the buffer (blocks without rows write zeros)
-    hipLaunchKernelGGL((k_linear_fwd<TO, TI, BN, ST>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((k_linear_fwd<TO, TI, BN, ST, STG>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
     EC_HIP(hipGetLastError());
     return EC_OK;
 }
