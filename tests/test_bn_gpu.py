@@ -404,6 +404,16 @@ def test_disc_rows_equals_cat_of_one_hots(B, T, N, A):
     eye = th.eye(N, device="cuda").expand(B, T, N, N)
     want = th.cat([obs, eye, th.nn.functional.one_hot(actions.squeeze(-1), num_classes=A).float()], dim=-1).reshape(-1, 9 + N + A)
     assert got.shape == want.shape and th.equal(got, want)
+    # an out-of-range action sets nothing; rows wider than the staged form takes (obs_dim > 63) go the direct way
+    bad = actions.clone()
+    bad.view(-1)[::3] = A + 5
+    bad.view(-1)[1::7] = -1
+    got_bad = linear_device.disc_rows(obs, bad, N, A)
+    keep = ((bad >= 0) & (bad < A)).reshape(-1, 1).float()
+    assert th.equal(got_bad[:, :9 + N], want[:, :9 + N]) and th.equal(got_bad[:, 9 + N:], want[:, 9 + N:] * keep)
+    wide = th.randn(B, T, N, 70, generator=gen).cuda()
+    want_w = th.cat([wide, eye, th.nn.functional.one_hot(actions.squeeze(-1), num_classes=A).float()], dim=-1).reshape(-1, 70 + N + A)
+    assert th.equal(linear_device.disc_rows(wide, actions, N, A), want_w)
     vp = lambda t: C.c_void_p(t.data_ptr())
     stream = C.c_void_p(th.cuda.current_stream().cuda_stream)
     assert _abi.lib().ec_disc_rows(vp(obs), vp(actions), B * T * N, 9, 0, A, vp(got), stream) != 0

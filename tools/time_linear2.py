@@ -31,3 +31,13 @@ with th.no_grad():
         b.record()
         th.cuda.synchronize()
         print("%s: %.3f ms" % (name, a.elapsed_time(b) / 5))
+    obs = th.randn(rows, 9, device="cuda")
+    acts = th.randint(0, 11, (rows,), device="cuda")
+    for _ in range(2):
+        linear_device.disc_rows(obs.view(-1, 10, 9), acts.view(-1, 10), 10, 11)
+    a.record()
+    for _ in range(5):
+        linear_device.disc_rows(obs.view(-1, 10, 9), acts.view(-1, 10), 10, 11)
+    b.record()
+    th.cuda.synchronize()
+    print("ec_disc_rows (10 nodes): %.3f ms" % (a.elapsed_time(b) / 5))
