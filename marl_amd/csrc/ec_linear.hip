@@ -38,7 +38,10 @@ struct LinArgs {
 // STG (K = 32 TI exactly, rows 16-byte aligned): the wave's 32 x K tile comes in as whole 1 KB runs -- lane l fetches the
 // tile's 16-byte pieces l, l + 64, .. -- and is handed to the row-per-lane order through a padded LDS tile; the next tile's
 // pieces are requested before this tile's MFMAs.  (Row-per-lane reads fetch 16 bytes of each of 32 rows per instruction:
-// 32 lines touched for 1 KB, and the 64 -> 32 and 32 -> 1 layers ran at 3.0 / 2.1 TB/s.)
+// 32 lines touched for 1 KB, and the 64 -> 32 and 32 -> 1 layers ran at 3.0 / 2.1 TB/s.)  Measured at 4.1 M rows: 64 -> 32
+// 0.37 -> 0.30 ms, 128 -> 64 1.08 -> 0.87 ms, 128 -> 30 0.67 -> 0.58 ms, 96 -> 128 1.33 -> 1.15 ms; with the BN prologue
+// 64 -> 32 0.52 -> 0.39 ms but 128 -> 64 1.15 -> 1.30 ms (one block of 100 KB per CU against three rolled waves per SIMD),
+// so BN instantiations with more than 64 inputs keep the rolled row-per-lane loads.
 template <int TO, int TI, bool BN, bool ST, bool STG = false>   // ST: the plain layer with the statistics epilogue (BN takes it at run time)
 __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
     extern __shared__ __align__(16) float lds[];
@@ -135,7 +138,7 @@ __global__ void __launch_bounds__(256) k_linear_fwd(LinArgs p) {
                 }
             }
         };
-        constexpr bool ROLL = TI >= 3 && (BN || TO == 1);
+        constexpr bool ROLL = !STG && TI >= 3 && (BN || TO == 1);   // (staged: the rows wait in LDS, nothing to keep in flight)
         constexpr int UNR_T = ROLL ? 1 : TI;
         float4 xa[4], xn[4];
         if (ROLL) load_x(0, xa);
@@ -583,7 +586,7 @@ __global__ void __launch_bounds__(256) k_disc_rows(const float* __restrict__ obs
 
 template <int TO, int TI, bool BN, bool ST, bool STG = false>
 int launch_linear(const LinArgs& a, hipStream_t stream) {
-    if constexpr (TI <= 2 && !STG) {   // the staged row load where it applies (header of k_linear_fwd)
+    if constexpr (!STG && (TI <= 2 || !BN)) {   // the staged row load where it applies and wins (header of k_linear_fwd)
         if (a.K == 32 * TI && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0) return launch_linear<TO, TI, BN, ST, true>(a, stream);
     }
     const size_t lds = sizeof(float) * ((size_t)16 * TI * TO * 64 + 64 * TO + 64 * TI + (STG ? 4 * 32 * (32 * TI + 4) : 0));

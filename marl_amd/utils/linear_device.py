@@ -31,10 +31,12 @@ def wgrad(gy, x):
 
 
 def fwd_ok(x, w):
-    """shapes for which ec_linear_fwd beats hipBLASLt (measured, tools/bench_linear.py): up to 64 inputs; with 128 the
-    row-per-lane reads lose"""
+    """shapes for which ec_linear_fwd beats hipBLASLt (measured, tools/bench_linear.py): up to 64 inputs, and 96 or 128
+    (whole 32-input tiles: the rows then come in through the staged load; 128 -> 64 0.87 against 0.95 ms at 4.1 M rows);
+    other widths above 64 read row-per-lane and lose"""
     return (x.is_cuda and w.is_cuda and x.dtype == th.float32 and w.dtype == th.float32 and x.dim() == 2 and w.dim() == 2
-            and x.shape[1] == w.shape[1] and 1 <= x.shape[1] <= 64 and 1 <= w.shape[0] <= 128 and not th.is_grad_enabled())
+            and x.shape[1] == w.shape[1] and (1 <= x.shape[1] <= 64 or (x.shape[1] in (96, 128) and x.data_ptr() % 16 == 0))
+            and 1 <= w.shape[0] <= 128 and not th.is_grad_enabled())
 
 
 def fwd(x, w, b=None, want_stats=False):
