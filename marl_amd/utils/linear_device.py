@@ -7,6 +7,7 @@ import torch as th
 from marl_amd import _abi
 
 N_PARTIALS = 512  # blocks of four waves: two per CU
+FUSE2_MAX_K = 32   # widest input for which ec_linear2_fwd_bn is the product's choice (fwd2_bn_ok)
 
 
 def wgrad_ok(gy, x):
@@ -108,9 +109,10 @@ def fwd_stats_from_moments(x, w, b):
 def fwd2_bn_ok(x, w1, w2):
     """shapes for which ec_linear2_fwd_bn wins: [rows, <= 32] -> 128 -> 64 (the GAIL discriminator's first two layers at
     hidden_dim 64 and 10 nodes).  The kernel takes up to 96 inputs, but beyond one 32-input tile it spills and loses to
-    the layer-by-layer kernels (8.2 M rows x 90 inputs, the 40-node shape: 8.3 ms against 5.5; tools/prof_reward_pass.sh)"""
+    the layer-by-layer kernels (8.2 M rows x 90 inputs, the 40-node shape: 8.3 ms against 5.5, tools/prof_reward_pass.sh;
+    4.1 M rows x 50 inputs, 20 nodes: reward pass 3.03 ms against 2.86 with FUSE2_MAX_K = 64, tools/bench_reward_pass.py)"""
     return (x.is_cuda and w1.is_cuda and w2.is_cuda and x.dtype == w1.dtype == w2.dtype == th.float32 and x.dim() == 2
-            and w1.dim() == 2 and w2.dim() == 2 and x.shape[1] == w1.shape[1] and 1 <= x.shape[1] <= 32
+            and w1.dim() == 2 and w2.dim() == 2 and x.shape[1] == w1.shape[1] and 1 <= x.shape[1] <= FUSE2_MAX_K
             and tuple(w1.shape[:1]) == (128,) and tuple(w2.shape) == (64, 128) and not th.is_grad_enabled())
 
 

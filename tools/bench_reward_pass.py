@@ -13,6 +13,7 @@ import torch as th  # noqa: E402
 import marl_amd.rl.policy_gradient_rl.gail.gail_network as gn  # noqa: E402
 from marl_amd.utils import linear_device  # noqa: E402
 
+linear_device.FUSE2_MAX_K = int(os.environ.get("FUSE2_MAX_K", linear_device.FUSE2_MAX_K))
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4096000
 nodes = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 args = SimpleNamespace(obs_shape=9, n_agents=nodes, n_actions=nodes + 1, hidden_dim=64, activate_fun="relu")
