@@ -7,6 +7,10 @@
 // ec_mfma.h (the lane index is the output, as there); and the accumulator leaves lane (out j, half h) holding 16 rows of
 // output j -- so every store instruction writes 32 consecutive floats of two rows: whole 128-byte lines.  (The same
 // kernel with outputs as M, as the fused learner kernels have it, stores 16-byte pieces and runs at hipBLASLt's rate.)
+//
+// Also here (round 3): k_linear2_fwd_bn, the discriminator's first two layers in one kernel for the reward pass (the
+// 128-wide tensor between them stays in registers); k_moments, the moments of the input rows from which the first
+// BatchNorm's statistics follow without computing the layer; k_disc_rows, the (obs | id | action) input rows.
 #include "ec_mfma.h"
 
 namespace {
