@@ -238,7 +238,7 @@ def test_linear_fwd_bn_equals_tail_then_linear(rows, k_in, c_out, p):
 
 
 @pytest.mark.parametrize("rows,k_in,p", [(70001, 30, 0.3), (4097, 50, 0.3), (33, 90, 0.0), (2, 9, 0.5), (100003, 64, 0.25),
-                                         (1, 30, 0.3), (262144 + 5, 96, 0.3)])
+                                         (1, 30, 0.3), (262144 + 5, 96, 0.3), (4096000, 30, 0.3)])   # (the last: GAIL's full size)
 def test_linear2_fwd_bn_equals_two_kernels(rows, k_in, p):
     """ec_linear2_fwd_bn (layers 1 and 2 of the GAIL discriminator in one kernel, layer 1's 128-wide output in registers)
     against the two kernels it replaces -- ec_linear_fwd, then ec_linear_fwd_bn -- for the same seed: y bit for bit (same
@@ -287,7 +287,7 @@ def test_linear2_fwd_bn_equals_two_kernels(rows, k_in, p):
 
 
 @pytest.mark.parametrize("rows,k_in", [(1, 30), (33, 30), (100003, 30), (70001, 50), (5000, 9), (40000, 90), (8192, 32),
-                                        (3000, 96), (262144 + 7, 64)])
+                                        (3000, 96), (262144 + 7, 64), (4096000, 30)])
 def test_row_moments_give_layer_statistics(rows, k_in):
     """ec_row_moments (sums of d and d d^T over the rows, d = x[row] - x[0], the row index as the MFMA's K dimension)
     against float64, with columns far from zero mean and one-hot columns as the discriminator's rows have them; and the
